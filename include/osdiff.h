@@ -1,0 +1,187 @@
+/*
+ * osdiff.h -- C ABI of libosdiff.so, the MI355X (gfx950) implementation of the
+ * diffusion hot path of rare-resilience-ai/Osteosarcoma_DiffusionModel.
+ *
+ * The reference has no FFI boundary of its own: its hot path is the Python object
+ * API of models/diffusion.py, utils/train.py and utils/generate.py.  Each entry
+ * point below names the reference function (file:line, relative to the reference
+ * tree) whose arithmetic it replaces; the Python shim in
+ * osteosarcoma_diffusionmodel_amd/ keeps the reference's class and method names
+ * and calls these through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 (OSD_OK) or a negative OSD_E* code; no exceptions,
+ *     no aborts.  osd_last_error() returns the message of the last failure on the
+ *     calling thread.
+ *   - all tensors are row-major contiguous fp32 unless stated; "dev" pointers are
+ *     device memory of the handle's device, "host" pointers are host memory.
+ *   - the caller owns every tensor; the library borrows pointers for the duration
+ *     of a call, except the parameter pointers given to osd_load_weights(), which
+ *     are borrowed until the next osd_load_weights() / osd_destroy().
+ *   - all work is enqueued on the handle's stream (osd_set_stream) and is
+ *     asynchronous unless stated; calls on one handle are not re-entrant.
+ *   - no CPU fallback exists: without a HIP device every compute call fails.
+ */
+#ifndef OSDIFF_H
+#define OSDIFF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSD_VERSION 100 /* 0.1.0 */
+
+#define OSD_OK            0
+#define OSD_EINVAL       -1 /* bad argument / shape (Python: ValueError)        */
+#define OSD_ENOMEM       -2 /* allocation failed                                 */
+#define OSD_EHIP         -3 /* HIP runtime error (Python: RuntimeError)          */
+#define OSD_ESTATE       -4 /* call order: schedule / weights not loaded         */
+#define OSD_EUNSUPPORTED -5 /* architecture outside what the kernels cover       */
+
+#define OSD_MAX_HIDDEN 8
+
+/* flags */
+#define OSD_F_GRAPH      1 /* replay the reverse step from a captured hipGraph   */
+#define OSD_F_TRAIN_MODE 2 /* dropout active (model.train())                     */
+#define OSD_F_SYNC       4 /* synchronise the handle's stream before returning   */
+
+typedef struct osd_handle osd_handle;
+
+/* Constructor arguments of BiologyAwareDiffusionModel (models/diffusion.py:264-301). */
+typedef struct osd_config {
+  int32_t mutation_dim;
+  int32_t expression_dim;
+  int32_t pathway_dim;
+  int32_t condition_dim;
+  int32_t time_dim;                    /* config.model.latent_dim; cond width is time_dim/2 and must be 64 */
+  int32_t n_hidden;                    /* len(config.model.hidden_dims)                    */
+  int32_t hidden_dims[OSD_MAX_HIDDEN]; /* each divisible by 8 (GroupNorm(8, C))            */
+  int32_t num_steps;                   /* config.model.diffusion.num_steps (T)             */
+  float   dropout_p;                   /* config.model.gnn.dropout (models/diffusion.py:294)*/
+  int32_t device;                      /* HIP device ordinal                                */
+} osd_config;
+
+int         osd_version(void);
+const char *osd_last_error(void);
+
+/* Number of trainable parameter tensors for this architecture (52 at n_hidden == 3),
+ * in the order of BiologyAwareDiffusionModel.named_parameters(); 0 on bad config. */
+int osd_num_params(const osd_config *cfg);
+/* Element count of parameter i (same order); -1 on bad index. */
+int64_t osd_param_numel(const osd_config *cfg, int i);
+
+/* models/diffusion.py:264-310 (construction).  Allocates schedule tables and streams. */
+int osd_create(const osd_config *cfg, osd_handle **out);
+int osd_destroy(osd_handle *h);
+
+/* Bind the HIP stream (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream). */
+int osd_set_stream(osd_handle *h, void *hip_stream);
+
+/* Tunables: "chunk_rows" (rows per sampling chunk), "n_streams" (chunks in flight). */
+int osd_set_option(osd_handle *h, const char *name, int64_t value);
+
+/* Schedule + time-embedding tables, computed by the host with the reference's own
+ * fp32 expressions so they are bit-identical (models/diffusion.py:299-326, 131-137,
+ * 401-419).  All host pointers:
+ *   sqrt_ac[T], sqrt_1m_ac[T]   buffers used by q_sample (:337-338)
+ *   post_coef[T*6]              per-step scalars of p_sample (:401-419), layout of
+ *                               oracle/diffusion_oracle.py:posterior_coefficients
+ *   time_emb[T*time_dim]        TimeEmbedding(t/T) rows for t = 0..T-1 (:131-137) */
+int osd_set_schedule(osd_handle *h, const float *sqrt_ac, const float *sqrt_1m_ac,
+                     const float *post_coef, const float *time_emb);
+
+/* nn.Module parameters (models/diffusion.py:283-295): n == osd_num_params() device
+ * pointers in named_parameters() order.  Borrowed; derived tables (time_proj applied
+ * to the time-embedding table) are recomputed on the handle's stream.  Call again
+ * after any in-place parameter update. */
+int osd_load_weights(osd_handle *h, const float *const *params, int n);
+
+/* DiffusionUNet.forward in eval/train mode on n rows (models/diffusion.py:210-256)
+ * including ConditionalEmbedding (:101-114):  eps[n][D].
+ *   t_index  dev int32[n] per-row timestep index, or NULL -> every row uses t_all
+ *   masks    train mode only: dev float 0/1 keep-masks, one [n][C] per block in
+ *            execution order (n_blocks pointers, host array), or NULL -> Philox(seed) */
+int osd_denoiser_forward(osd_handle *h, const float *x, const int32_t *t_index, int32_t t_all,
+                         const float *cond, int64_t n, float *eps, int flags,
+                         const float *const *masks, uint64_t seed);
+
+/* q_sample (models/diffusion.py:328-342): x_t = sqrt_ac[t]*x0 + sqrt_1m_ac[t]*noise.
+ * noise_in NULL -> Philox(seed, row_offset) normals, written to noise_out. */
+int osd_q_sample(osd_handle *h, const float *x0, const int32_t *t_index, const float *noise_in,
+                 int64_t n, uint64_t seed, int64_t row_offset, float *x_t, float *noise_out);
+
+/* p_sample (models/diffusion.py:382-425): one reverse step at python-int t.
+ * z NULL -> Philox(seed,row_offset,t).  In-place (x_out == x_t) is allowed. */
+int osd_p_sample_step(osd_handle *h, const float *x_t, int32_t t, const float *cond, const float *z,
+                      int64_t n, uint64_t seed, int64_t row_offset, float *x_out, int flags);
+
+/* sample (models/diffusion.py:427-449) + binarisation of utils/generate.py:135.
+ *   x_T     dev [n][D] start noise or NULL -> Philox
+ *   noises  dev [T-1][n][D] in draw order (t = T-1 .. 1) or NULL -> Philox
+ *   x_out   dev [n][D]
+ *   mut_mask_out  dev float [n][mutation_dim] = (x_out[:, :mutation_dim] > 0.5) or NULL
+ * Rows are split into chunks that run the whole T-step chain independently on the
+ * handle's internal streams; row_offset makes Philox draws independent of sharding. */
+int osd_sample_chain(osd_handle *h, const float *cond, int64_t n, const float *x_T,
+                     const float *noises, uint64_t seed, int64_t row_offset, float *x_out,
+                     float *mut_mask_out, int flags);
+
+/* Training forward+backward (models/diffusion.py:344-380 + loss.backward(),
+ * utils/train.py:236-239): loss (dev float[1]) and gradients of all parameters.
+ *   t_index   dev int32[n] or NULL -> Philox randint
+ *   noise     dev [n][D] or NULL -> Philox
+ *   masks     keep-masks as in osd_denoiser_forward, or NULL -> Philox / none in eval
+ *   grads     n_params device pointers (host array); overwritten (not accumulated)
+ *   loss_scale  multiplies the gradients (1.0 for plain backward)
+ *   events/n_events  optional hipEvent_t array recorded on the handle's stream as
+ *             each gradient bucket (see osd_grad_bucket) becomes final, for
+ *             overlapping the RCCL all-reduce with the rest of backward */
+int osd_train_loss_fwd_bwd(osd_handle *h, const float *x0, const float *cond, int64_t n,
+                           const int32_t *t_index, const float *noise, const float *const *masks,
+                           uint64_t seed, int64_t row_offset, int flags, float *loss_out,
+                           float *const *grads, float loss_scale, void *const *events, int n_events);
+
+/* Gradient buckets in the order backward finalises them: bucket b covers parameters
+ * [first, last] (indices in named_parameters() order).  Returns the bucket count. */
+int osd_grad_buckets(const osd_config *cfg, int32_t *first, int32_t *last, int max_buckets);
+
+/* MixupAugmentation.__call__ (utils/train.py:108-120): out = lam*v + (1-lam)*v[perm]
+ * for data[n][D], conditions[n][cond_dim], survival[n]; perm dev int64[n]. */
+int osd_mixup(osd_handle *h, const float *data, const float *cond, const float *surv,
+              const int64_t *perm, float lam, int64_t n, float *data_out, float *cond_out,
+              float *surv_out);
+
+/* clip_grad_norm_(max_norm) + AdamW.step (utils/train.py:242-244, 169-173) over flat
+ * contiguous buffers of `numel` floats.  step is the 1-based count after increment.
+ * grad_norm_out (dev float[1], may be NULL) receives the pre-clip global L2 norm.
+ * max_norm <= 0 disables clipping. */
+int osd_clip_adamw_step(osd_handle *h, float *param, float *grad, float *exp_avg, float *exp_avg_sq,
+                        int64_t numel, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, float max_norm, int64_t step, float *grad_norm_out);
+
+/* ---- building blocks, exported for the parity tests ------------------------ */
+/* y[n][N] = act(x[n][K] @ w[N][K]^T + b), act = identity (silu=0) or SiLU. */
+int osd_op_linear(osd_handle *h, const float *x, const float *w, const float *b, int64_t n, int K,
+                  int N, int silu, float *y);
+/* Linear -> GroupNorm(8) -> SiLU, one half of _make_block (models/diffusion.py:200-203).
+ * x2/K2: optional second K panel (concat-free decoder input, :250). */
+int osd_op_linear_gn_silu(osd_handle *h, const float *x, int K1, const float *x2, int K2,
+                          const float *w, const float *b, const float *gamma, const float *beta,
+                          int64_t n, int N, float *y);
+/* C[p][f] (+)= sum_k A(f,k) B(p,k), C row-major [P][F] with leading dimension ldc;
+ * a_kc/b_kc: operand stored [row][k] (1) or [k][row] (0).  Forward Linear is (1,1),
+ * dgrad (0,1), wgrad (0,0). */
+int osd_op_gemm(osd_handle *h, const float *A, int lda, int a_kc, const float *B, int ldb, int b_kc,
+                int F, int P, int K, float *C, int ldc, int accumulate);
+/* out[rows][cols] standard normals from the library's Philox stream, addressed by
+ * (seed, row_offset + row, col/4, step, kind): kind 0 = the z of p_sample at t == step
+ * (step == T is x_T), 1 = the eps of q_sample (step 0), >= 2 = user streams. */
+int osd_op_randn(osd_handle *h, float *out, int64_t rows, int cols, uint64_t seed,
+                 int64_t row_offset, uint32_t step, uint32_t kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSDIFF_H */

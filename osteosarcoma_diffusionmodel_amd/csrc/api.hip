@@ -1,0 +1,577 @@
+// api.hip -- C ABI of libosdiff.so (include/osdiff.h): handle management, the denoiser
+// forward pass, q_sample / p_sample / the hipGraph-replayed reverse chain.
+// Training entry points live in train.hip.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <new>
+#include "handle.h"
+#include "kernels.h"
+#include "fwd.h"
+#include "launch.h"
+
+namespace osd {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+std::vector<KernelReg>& kernel_registry() {
+  static std::vector<KernelReg> r;
+  return r;
+}
+hipError_t prepare_kernels() {
+  for (const KernelReg& k : kernel_registry()) {
+    hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+int build_arch(const osd_config& c, Arch* a) {
+  if (c.mutation_dim < 0 || c.expression_dim < 0 || c.pathway_dim < 0 || c.condition_dim <= 0) { set_error("bad feature dims"); return OSD_EINVAL; }
+  a->D = c.mutation_dim + c.expression_dim + c.pathway_dim;
+  if (a->D <= 0) { set_error("data_dim must be positive"); return OSD_EINVAL; }
+  if (c.n_hidden < 1 || c.n_hidden > OSD_MAX_HIDDEN) { set_error("n_hidden must be in [1,%d]", OSD_MAX_HIDDEN); return OSD_EINVAL; }
+  if (c.num_steps < 1) { set_error("num_steps must be >= 1"); return OSD_EINVAL; }
+  if (c.time_dim < 4 || (c.time_dim & 1)) { set_error("time_dim (latent_dim) must be even and >= 4"); return OSD_EINVAL; }
+  // models/diffusion.py:285 hard-wires the condition embedding width to 64 while cond_proj
+  // expects latent_dim // 2 inputs (:292): only latent_dim 128/129 constructs a working model.
+  if (c.time_dim / 2 != 64) { set_error("latent_dim // 2 must equal 64 (reference ConditionalEmbedding width)"); return OSD_EINVAL; }
+  if (!(c.dropout_p >= 0.f && c.dropout_p < 1.f)) { set_error("dropout must be in [0,1)"); return OSD_EINVAL; }
+  a->cond_dim = c.condition_dim;
+  a->time_dim = c.time_dim;
+  a->cond_width = 64;
+  a->T = c.num_steps;
+  a->hidden.assign(c.hidden_dims, c.hidden_dims + c.n_hidden);
+  for (int hdim : a->hidden) {
+    if (hdim <= 0 || hdim % 8) { set_error("hidden dims must be positive multiples of 8 (GroupNorm(8, C))"); return OSD_EINVAL; }
+    if (!gn_width_supported(hdim / 8)) { set_error("hidden dim %d: group width %d is outside the fused kernels (power of two in [4,128])", hdim, hdim / 8); return OSD_EUNSUPPORTED; }
+  }
+  const int L = c.n_hidden;
+  a->H0 = a->hidden[0];
+  a->n_enc = L - 1;
+  a->n_blocks = 2 * (L - 1) + 1;
+  a->layers.clear();
+  a->block_out.clear();
+  ParamMap& pm = a->pm;
+  pm.numel.clear();
+  int idx = 0;
+  auto P = [&](int64_t n) { pm.numel.push_back(n); return idx++; };
+  pm.ce0_w = P((int64_t)64 * c.condition_dim); pm.ce0_b = P(64);
+  pm.ce2_w = P(64 * 64); pm.ce2_b = P(64);
+  pm.in_w = P((int64_t)a->H0 * a->D); pm.in_b = P(a->H0);
+  pm.cp_w = P((int64_t)a->H0 * (c.time_dim / 2)); pm.cp_b = P(a->H0);
+  pm.tp_w = P((int64_t)a->H0 * c.time_dim); pm.tp_b = P(a->H0);
+  int bi = 0;
+  auto block = [&](int k1, int k2, int n) {
+    LayerDesc l1{k1, k2, n, 0, 0, 0, 0, n / 8, bi, 0};
+    l1.w = P((int64_t)n * (k1 + k2)); l1.b = P(n); l1.gamma = P(n); l1.beta = P(n);
+    LayerDesc l2{n, 0, n, 0, 0, 0, 0, n / 8, bi, 1};
+    l2.w = P((int64_t)n * n); l2.b = P(n); l2.gamma = P(n); l2.beta = P(n);
+    a->layers.push_back(l1); a->layers.push_back(l2);
+    a->block_out.push_back(n);
+    ++bi;
+  };
+  int cin = a->hidden[0];
+  for (int i = 1; i < L; ++i) { block(cin, 0, a->hidden[i]); cin = a->hidden[i]; }
+  block(cin, 0, cin);
+  int cur = a->hidden[L - 1];
+  for (int i = L - 2; i >= 0; --i) { block(cur, a->hidden[i + 1], a->hidden[i]); cur = a->hidden[i]; }
+  pm.out_w = P((int64_t)a->D * cur); pm.out_b = P(a->D);
+  pm.n_params = idx;
+  int64_t per = 64 + 64 + 2 * (int64_t)a->H0;
+  for (int n : a->block_out) per += 2 * (int64_t)n;
+  a->act_floats_per_row = per;
+  return OSD_OK;
+}
+
+static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+int ensure_arena(Slot* s, int64_t floats) {
+  if (s->arena_floats >= floats) return OSD_OK;
+  if (s->arena) { hipError_t e = hipFree(s->arena); (void)e; s->arena = nullptr; s->arena_floats = 0; }
+  void* p = nullptr;
+  if (hipMalloc(&p, (size_t)floats * 4) != hipSuccess) { set_error("hipMalloc of %lld bytes failed", (long long)floats * 4); return OSD_ENOMEM; }
+  s->arena = (float*)p;
+  s->arena_floats = floats;
+  return OSD_OK;
+}
+
+// Carve forward activations for n rows out of `base`; returns floats used.
+int64_t carve_fwd(const Arch& a, float* base, int64_t n, bool train, FwdWs* ws) {
+  int64_t off = 0;
+  auto take = [&](int64_t floats) { float* p = base ? base + off : nullptr; off += align_up(floats, 64); return p; };
+  ws->ce1 = take(n * 64); ws->ce2 = take(n * 64);
+  ws->cproj = take(n * a.H0); ws->h0 = take(n * a.H0);
+  ws->mid.resize(a.n_blocks); ws->out.resize(a.n_blocks);
+  ws->z1.assign(a.n_blocks, nullptr); ws->z2.assign(a.n_blocks, nullptr);
+  ws->st1.assign(a.n_blocks, nullptr); ws->st2.assign(a.n_blocks, nullptr);
+  for (int b = 0; b < a.n_blocks; ++b) {
+    const int64_t c = a.block_out[b];
+    ws->mid[b] = take(n * c); ws->out[b] = take(n * c);
+    if (train) {
+      ws->z1[b] = take(n * c); ws->z2[b] = take(n * c);
+      ws->st1[b] = take(n * 16); ws->st2[b] = take(n * 16);
+    }
+  }
+  return off;
+}
+
+// ConditionalEmbedding + cond_proj (models/diffusion.py:101-105, 226): cproj[n][H0]
+int run_cond(osd_handle* h, hipStream_t s, const float* cond, int64_t n, const FwdWs& ws) {
+  const Arch& a = h->arch;
+  const ParamMap& pm = a.pm;
+  GemmArgs g{};
+  g.A = h->params[pm.ce0_w]; g.lda = a.cond_dim; g.B0 = cond; g.ldb0 = a.cond_dim; g.K0 = a.cond_dim;
+  g.F = 64; g.P = (int)n; g.K = a.cond_dim;
+  OSD_HIP(launch_linear(s, g, true, true, h->params[pm.ce0_b], ws.ce1, 64, true, false));
+  g.A = h->params[pm.ce2_w]; g.lda = 64; g.B0 = ws.ce1; g.ldb0 = 64; g.K0 = 64; g.K = 64;
+  OSD_HIP(launch_linear(s, g, true, true, h->params[pm.ce2_b], ws.ce2, 64, false, false));
+  g.A = h->params[pm.cp_w]; g.lda = 64; g.B0 = ws.ce2; g.ldb0 = 64; g.K0 = 64; g.K = 64; g.F = a.H0;
+  OSD_HIP(launch_linear(s, g, true, true, h->params[pm.cp_b], ws.cproj, a.H0, false, false));
+  return OSD_OK;
+}
+
+// input_proj + blocks (models/diffusion.py:229-251); result in ws.out[n_blocks-1].
+int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) {
+  const Arch& a = h->arch;
+  const ParamMap& pm = a.pm;
+  const int n = (int)in.n;
+  {
+    GemmArgs g{};
+    g.A = h->params[pm.in_w]; g.lda = a.D; g.B0 = in.x; g.ldb0 = in.ldx; g.K0 = a.D;
+    g.F = a.H0; g.P = n; g.K = a.D;
+    EpiInput::Args ea{h->params[pm.in_b], h->d_temb, a.H0, in.t_index, in.t_dev, in.t_imm, ws.cproj, a.H0, ws.h0, a.H0};
+    OSD_HIP(launch_input(s, g, ea));
+  }
+  const float* cur = ws.h0;
+  int cur_w = a.H0;
+  for (int b = 0; b < a.n_blocks; ++b) {
+    const LayerDesc& l1 = a.layers[2 * b];
+    const LayerDesc& l2 = a.layers[2 * b + 1];
+    GemmArgs g{};
+    g.A = h->params[l1.w]; g.lda = l1.K1 + l1.K2;
+    g.B0 = cur; g.ldb0 = cur_w; g.K0 = l1.K1;
+    if (l1.K2 > 0) {
+      const int skip_block = a.n_enc - 1 - (b - a.n_enc - 1);   // LIFO: decoder j pops encoder n_enc-1-j
+      g.B1 = ws.out[skip_block]; g.ldb1 = a.block_out[skip_block];
+    }
+    g.F = l1.N; g.P = n; g.K = l1.K1 + l1.K2;
+    GnArgs ga{};
+    ga.bias = h->params[l1.b]; ga.gamma = h->params[l1.gamma]; ga.beta = h->params[l1.beta];
+    ga.out = ws.mid[b]; ga.ldo = l1.N;
+    ga.z_out = in.save ? ws.z1[b] : nullptr; ga.ldz = l1.N; ga.stats = in.save ? ws.st1[b] : nullptr;
+    const bool drop = in.train && h->cfg.dropout_p > 0.f;
+    if (drop) {
+      ga.drop_mode = in.masks ? 1 : 2;
+      ga.mask = in.masks ? in.masks[b] : nullptr; ga.ldm = l1.N;
+      ga.keep_scale = (float)(1.0 / (1.0 - (double)h->cfg.dropout_p)); ga.p_drop = h->cfg.dropout_p;
+      ga.seed = in.seed; ga.row_offset = in.row_offset; ga.step = in.drop_step; ga.tag = TAG_DROPOUT + (uint32_t)b;
+      ga.step_dev = in.drop_step_dev;
+      OSD_HIP(launch_gn_silu_drop(s, g, l1.gw, ga));
+    } else {
+      OSD_HIP(launch_gn_silu(s, g, l1.gw, ga));
+    }
+    GemmArgs g2{};
+    g2.A = h->params[l2.w]; g2.lda = l2.K1; g2.B0 = ws.mid[b]; g2.ldb0 = l1.N; g2.K0 = l2.K1;
+    g2.F = l2.N; g2.P = n; g2.K = l2.K1;
+    GnArgs gb{};
+    gb.bias = h->params[l2.b]; gb.gamma = h->params[l2.gamma]; gb.beta = h->params[l2.beta];
+    gb.out = ws.out[b]; gb.ldo = l2.N;
+    gb.z_out = in.save ? ws.z2[b] : nullptr; gb.ldz = l2.N; gb.stats = in.save ? ws.st2[b] : nullptr;
+    OSD_HIP(launch_gn_silu(s, g2, l2.gw, gb));
+    cur = ws.out[b];
+    cur_w = l2.N;
+  }
+  return OSD_OK;
+}
+
+GemmArgs output_proj_args(osd_handle* h, const FwdWs& ws, int64_t n) {
+  const Arch& a = h->arch;
+  const int last = a.n_blocks - 1;
+  GemmArgs g{};
+  g.A = h->params[a.pm.out_w]; g.lda = a.block_out[last];
+  g.B0 = ws.out[last]; g.ldb0 = a.block_out[last]; g.K0 = a.block_out[last];
+  g.F = a.D; g.P = (int)n; g.K = a.block_out[last];
+  return g;
+}
+
+int check_ready(osd_handle* h) {
+  if (!h) { set_error("null handle"); return OSD_EINVAL; }
+  if (!h->have_schedule) { set_error("osd_set_schedule has not been called"); return OSD_ESTATE; }
+  if (!h->have_weights) { set_error("osd_load_weights has not been called"); return OSD_ESTATE; }
+  return OSD_OK;
+}
+
+int check_rows(int64_t n) {
+  if (n < 0 || n > 0x7fffffff / 2) { set_error("row count %lld out of range", (long long)n); return OSD_EINVAL; }
+  return OSD_OK;
+}
+
+}  // namespace osd
+
+using namespace osd;
+
+extern "C" {
+
+int osd_version(void) { return OSD_VERSION; }
+const char* osd_last_error(void) { return g_err; }
+
+int osd_num_params(const osd_config* cfg) {
+  if (!cfg) return 0;
+  Arch a;
+  if (build_arch(*cfg, &a) != OSD_OK) return 0;
+  return a.pm.n_params;
+}
+
+int64_t osd_param_numel(const osd_config* cfg, int i) {
+  if (!cfg) return -1;
+  Arch a;
+  if (build_arch(*cfg, &a) != OSD_OK) return -1;
+  if (i < 0 || i >= a.pm.n_params) return -1;
+  return a.pm.numel[i];
+}
+
+int osd_create(const osd_config* cfg, osd_handle** out) {
+  if (!cfg || !out) { set_error("null argument"); return OSD_EINVAL; }
+  *out = nullptr;
+  Arch a;
+  OSD_TRY(build_arch(*cfg, &a));
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available: libosdiff has no CPU fallback"); return OSD_EHIP; }
+  if (cfg->device < 0 || cfg->device >= ndev) { set_error("device %d out of range (%d devices)", cfg->device, ndev); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(cfg->device));
+  OSD_HIP(prepare_kernels());
+  osd_handle* h = new (std::nothrow) osd_handle();
+  if (!h) { set_error("out of host memory"); return OSD_ENOMEM; }
+  h->cfg = *cfg;
+  h->arch = a;
+  const int T = a.T;
+  OSD_HIP(hipMalloc((void**)&h->d_sqrt_ac, T * 4));
+  OSD_HIP(hipMalloc((void**)&h->d_sqrt_1m, T * 4));
+  OSD_HIP(hipMalloc((void**)&h->d_coef, (size_t)T * 6 * 4));
+  OSD_HIP(hipMalloc((void**)&h->d_time_emb, (size_t)T * a.time_dim * 4));
+  OSD_HIP(hipMalloc((void**)&h->d_temb, (size_t)T * a.H0 * 4));
+  OSD_HIP(hipMalloc((void**)&h->main.t_dev, 64));
+  OSD_HIP(hipMalloc((void**)&h->loss_dev, 64));
+  OSD_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+  *out = h;
+  return OSD_OK;
+}
+
+static void free_slot(Slot& s, bool own_stream) {
+  hipError_t e;
+  if (s.exec) { e = hipGraphExecDestroy(s.exec); }
+  if (s.graph) { e = hipGraphDestroy(s.graph); }
+  if (s.arena) { e = hipFree(s.arena); }
+  if (s.t_dev) { e = hipFree(s.t_dev); }
+  if (s.done) { e = hipEventDestroy(s.done); }
+  if (own_stream && s.stream) { e = hipStreamDestroy(s.stream); }
+  (void)e;
+  s = Slot();
+}
+
+int osd_destroy(osd_handle* h) {
+  if (!h) return OSD_OK;
+  hipError_t e = hipSetDevice(h->cfg.device);
+  e = hipDeviceSynchronize();
+  for (auto& s : h->slots) free_slot(s, true);
+  free_slot(h->main, false);
+  float* bufs[] = {h->d_sqrt_ac, h->d_sqrt_1m, h->d_coef, h->d_time_emb, h->d_temb, h->train_arena, h->loss_dev};
+  for (float* p : bufs) if (p) e = hipFree(p);
+  if (h->normsq_dev) e = hipFree(h->normsq_dev);
+  if (h->fork_ev) e = hipEventDestroy(h->fork_ev);
+  (void)e;
+  delete h;
+  return OSD_OK;
+}
+
+int osd_set_stream(osd_handle* h, void* hip_stream) {
+  if (!h) { set_error("null handle"); return OSD_EINVAL; }
+  h->stream = (hipStream_t)hip_stream;
+  return OSD_OK;
+}
+
+int osd_set_option(osd_handle* h, const char* name, int64_t value) {
+  if (!h || !name) { set_error("null argument"); return OSD_EINVAL; }
+  if (!strcmp(name, "chunk_rows")) {
+    if (value < 1) { set_error("chunk_rows must be >= 1"); return OSD_EINVAL; }
+    h->chunk_rows = value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "n_streams")) {
+    if (value < 1 || value > 8) { set_error("n_streams must be in [1,8]"); return OSD_EINVAL; }
+    h->n_streams = (int)value;
+    return OSD_OK;
+  }
+  set_error("unknown option '%s'", name);
+  return OSD_EINVAL;
+}
+
+int osd_set_schedule(osd_handle* h, const float* sqrt_ac, const float* sqrt_1m_ac, const float* post_coef, const float* time_emb) {
+  if (!h || !sqrt_ac || !sqrt_1m_ac || !post_coef || !time_emb) { set_error("null argument"); return OSD_EINVAL; }
+  const Arch& a = h->arch;
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  OSD_HIP(hipMemcpy(h->d_sqrt_ac, sqrt_ac, a.T * 4, hipMemcpyHostToDevice));
+  OSD_HIP(hipMemcpy(h->d_sqrt_1m, sqrt_1m_ac, a.T * 4, hipMemcpyHostToDevice));
+  OSD_HIP(hipMemcpy(h->d_coef, post_coef, (size_t)a.T * 6 * 4, hipMemcpyHostToDevice));
+  OSD_HIP(hipMemcpy(h->d_time_emb, time_emb, (size_t)a.T * a.time_dim * 4, hipMemcpyHostToDevice));
+  h->have_schedule = true;
+  return OSD_OK;
+}
+
+int osd_load_weights(osd_handle* h, const float* const* params, int n) {
+  if (!h || !params) { set_error("null argument"); return OSD_EINVAL; }
+  const Arch& a = h->arch;
+  if (n != a.pm.n_params) { set_error("expected %d parameter tensors, got %d", a.pm.n_params, n); return OSD_EINVAL; }
+  if (!h->have_schedule) { set_error("osd_set_schedule must precede osd_load_weights"); return OSD_ESTATE; }
+  for (int i = 0; i < n; ++i)
+    if (!params[i]) { set_error("parameter %d is null", i); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  h->params.assign(params, params + n);
+  // t_emb table: time_proj(TimeEmbedding(t/T)) for every t (models/diffusion.py:222-223); all rows
+  // of a sampling step share t and training rows gather their t, so the Linear runs T times, not B.
+  GemmArgs g{};
+  g.A = h->params[a.pm.tp_w]; g.lda = a.time_dim; g.B0 = h->d_time_emb; g.ldb0 = a.time_dim; g.K0 = a.time_dim;
+  g.F = a.H0; g.P = a.T; g.K = a.time_dim;
+  OSD_HIP(launch_linear(h->stream, g, true, true, h->params[a.pm.tp_b], h->d_temb, a.H0, false, false));
+  h->have_weights = true;
+  return OSD_OK;
+}
+
+int osd_denoiser_forward(osd_handle* h, const float* x, const int32_t* t_index, int32_t t_all, const float* cond, int64_t n,
+                         float* eps, int flags, const float* const* masks, uint64_t seed) {
+  OSD_TRY(check_ready(h));
+  OSD_TRY(check_rows(n));
+  if (!x || !cond || !eps) { set_error("null tensor"); return OSD_EINVAL; }
+  const Arch& a = h->arch;
+  if (!t_index && (t_all < 0 || t_all >= a.T)) { set_error("t=%d outside [0,%d)", t_all, a.T); return OSD_EINVAL; }
+  if (n == 0) return OSD_OK;
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  FwdWs ws;
+  const int64_t need = carve_fwd(a, nullptr, n, false, &ws);
+  OSD_TRY(ensure_arena(&h->main, need));
+  carve_fwd(a, h->main.arena, n, false, &ws);
+  hipStream_t s = h->stream;
+  OSD_TRY(run_cond(h, s, cond, n, ws));
+  TrunkIn in{};
+  in.x = x; in.ldx = a.D; in.n = n; in.t_index = t_index; in.t_imm = t_all;
+  in.train = (flags & OSD_F_TRAIN_MODE) != 0; in.masks = masks; in.seed = seed;
+  OSD_TRY(run_trunk(h, s, ws, in));
+  GemmArgs g = output_proj_args(h, ws, n);
+  OSD_HIP(launch_linear(s, g, true, true, h->params[a.pm.out_b], eps, a.D, false, false));
+  if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
+  return OSD_OK;
+}
+
+int osd_q_sample(osd_handle* h, const float* x0, const int32_t* t_index, const float* noise_in, int64_t n, uint64_t seed,
+                 int64_t row_offset, float* x_t, float* noise_out) {
+  if (!h || !h->have_schedule) { set_error("schedule not set"); return OSD_ESTATE; }
+  OSD_TRY(check_rows(n));
+  if (!x0 || !t_index || !x_t) { set_error("null tensor"); return OSD_EINVAL; }
+  if (!noise_in && !noise_out) { set_error("noise_out is required when noise is generated"); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  OSD_HIP(launch_q_sample(h->stream, x0, t_index, h->d_sqrt_ac, h->d_sqrt_1m, noise_in, n, h->arch.D, seed, (uint32_t)row_offset, x_t, noise_out));
+  return OSD_OK;
+}
+
+int osd_p_sample_step(osd_handle* h, const float* x_t, int32_t t, const float* cond, const float* z, int64_t n, uint64_t seed,
+                      int64_t row_offset, float* x_out, int flags) {
+  OSD_TRY(check_ready(h));
+  OSD_TRY(check_rows(n));
+  if (!x_t || !cond || !x_out) { set_error("null tensor"); return OSD_EINVAL; }
+  const Arch& a = h->arch;
+  if (t < 0 || t >= a.T) { set_error("t=%d outside [0,%d)", t, a.T); return OSD_EINVAL; }
+  if (n == 0) return OSD_OK;
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  FwdWs ws;
+  const int64_t need = carve_fwd(a, nullptr, n, false, &ws);
+  OSD_TRY(ensure_arena(&h->main, need));
+  carve_fwd(a, h->main.arena, n, false, &ws);
+  hipStream_t s = h->stream;
+  OSD_TRY(run_cond(h, s, cond, n, ws));      // recomputed every step, as models/diffusion.py:395 does
+  TrunkIn in{};
+  in.x = x_t; in.ldx = a.D; in.n = n; in.t_imm = t;
+  in.train = (flags & OSD_F_TRAIN_MODE) != 0; in.seed = seed; in.row_offset = (uint32_t)row_offset; in.drop_step = (uint32_t)t;
+  OSD_TRY(run_trunk(h, s, ws, in));
+  GemmArgs g = output_proj_args(h, ws, n);
+  EpiPosterior::Args ea{};
+  ea.bias = h->params[a.pm.out_b]; ea.xin = x_t; ea.ldx = a.D; ea.xout = x_out; ea.ldo = a.D; ea.coef = h->d_coef;
+  ea.t_dev = nullptr; ea.t_imm = t; ea.z = z; ea.ldzz = a.D; ea.z_step_stride = 0; ea.t_first = t;
+  ea.seed = seed; ea.row_offset = (uint32_t)row_offset; ea.mut_mask = nullptr; ea.mutation_dim = 0;
+  OSD_HIP(launch_posterior(s, g, ea));
+  if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
+  return OSD_OK;
+}
+
+// Drop the slot's previous graph once everything replayed from it has finished.
+static int release_graph(Slot& sl) {
+  if (!sl.exec && !sl.graph) return OSD_OK;
+  OSD_HIP(hipStreamSynchronize(sl.stream));
+  if (sl.exec) OSD_HIP(hipGraphExecDestroy(sl.exec));
+  if (sl.graph) OSD_HIP(hipGraphDestroy(sl.graph));
+  sl.exec = nullptr;
+  sl.graph = nullptr;
+  return OSD_OK;
+}
+
+// One chunk of the reverse chain on one slot: rows [r0, r0+m).
+static int chain_chunk(osd_handle* h, Slot& sl, const float* cond, int64_t n_total, int64_t r0, int64_t m, const float* x_T,
+                       const float* noises, uint64_t seed, int64_t row_offset, float* x_out, float* mut_mask_out, int flags) {
+  const Arch& a = h->arch;
+  const int D = a.D, T = a.T;
+  hipStream_t s = sl.stream;
+  OSD_TRY(release_graph(sl));
+  FwdWs ws;
+  const int64_t need = carve_fwd(a, nullptr, m, false, &ws);
+  OSD_TRY(ensure_arena(&sl, need));
+  carve_fwd(a, sl.arena, m, false, &ws);
+  float* x = x_out + r0 * D;                 // the chain state lives in the output rows
+  const uint32_t roff = (uint32_t)(row_offset + r0);
+  const bool train = (flags & OSD_F_TRAIN_MODE) != 0;
+  // conditioning is loop-invariant in eval mode (no dropout inside the embedding MLP): hoisted
+  OSD_TRY(run_cond(h, s, cond + r0 * a.cond_dim, m, ws));
+  if (x_T) OSD_HIP(launch_copy2d(s, x_T + r0 * D, D, x, D, m, D));
+  else OSD_HIP(launch_fill_randn(s, x, D, m, D, seed, roff, (uint32_t)T, TAG_POSTERIOR));
+  OSD_HIP(launch_set_int(s, sl.t_dev, T - 1));
+
+  auto enqueue_step = [&](void) -> int {
+    TrunkIn in{};
+    in.x = x; in.ldx = D; in.n = m; in.t_dev = sl.t_dev;
+    in.train = train; in.seed = seed; in.row_offset = roff; in.drop_step_dev = sl.t_dev;
+    OSD_TRY(run_trunk(h, s, ws, in));
+    GemmArgs g = output_proj_args(h, ws, m);
+    EpiPosterior::Args ea{};
+    ea.bias = h->params[a.pm.out_b]; ea.xin = x; ea.ldx = D; ea.xout = x; ea.ldo = D; ea.coef = h->d_coef;
+    ea.t_dev = sl.t_dev; ea.t_imm = 0;
+    ea.z = noises ? noises + r0 * D : nullptr; ea.ldzz = D; ea.z_step_stride = (long long)n_total * D; ea.t_first = T - 1;
+    ea.seed = seed; ea.row_offset = roff;
+    ea.mut_mask = mut_mask_out ? mut_mask_out + r0 * h->cfg.mutation_dim : nullptr; ea.mutation_dim = h->cfg.mutation_dim;
+    OSD_HIP(launch_posterior(s, g, ea));
+    OSD_HIP(launch_add_int(s, sl.t_dev, -1));
+    return OSD_OK;
+  };
+
+  if (flags & OSD_F_GRAPH) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    OSD_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_step();
+    hipError_t ce = hipStreamEndCapture(s, &graph);
+    if (rc != OSD_OK) { if (graph) { hipError_t e = hipGraphDestroy(graph); (void)e; } return rc; }
+    OSD_HIP(ce);
+    OSD_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    // the exec object must outlive its launches: the slot keeps it until its next use
+    sl.graph = graph;
+    sl.exec = exec;
+    for (int it = 0; it < T; ++it) OSD_HIP(hipGraphLaunch(exec, s));
+  } else {
+    for (int it = 0; it < T; ++it) OSD_TRY(enqueue_step());
+  }
+  return OSD_OK;
+}
+
+int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x_T, const float* noises, uint64_t seed,
+                     int64_t row_offset, float* x_out, float* mut_mask_out, int flags) {
+  OSD_TRY(check_ready(h));
+  OSD_TRY(check_rows(n));
+  if (!cond || !x_out) { set_error("null tensor"); return OSD_EINVAL; }
+  if (n == 0) return OSD_OK;
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  const int64_t chunk = std::min<int64_t>(h->chunk_rows, n);
+  const int64_t n_chunks = (n + chunk - 1) / chunk;
+  const int n_slots = (int)std::min<int64_t>(h->n_streams, n_chunks);
+  while ((int)h->slots.size() < n_slots) {
+    Slot sl;
+    OSD_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+    OSD_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    OSD_HIP(hipMalloc((void**)&sl.t_dev, 64));
+    h->slots.push_back(sl);
+  }
+  // fork: slot streams wait for everything already queued on the caller's stream
+  OSD_HIP(hipEventRecord(h->fork_ev, h->stream));
+  for (int i = 0; i < n_slots; ++i) OSD_HIP(hipStreamWaitEvent(h->slots[i].stream, h->fork_ev, 0));
+  int rc = OSD_OK;
+  for (int64_t c = 0; c < n_chunks && rc == OSD_OK; ++c) {
+    const int64_t r0 = c * chunk;
+    const int64_t m = std::min<int64_t>(chunk, n - r0);
+    rc = chain_chunk(h, h->slots[c % n_slots], cond, n, r0, m, x_T, noises, seed, row_offset, x_out, mut_mask_out, flags);
+  }
+  // join
+  for (int i = 0; i < n_slots; ++i) {
+    hipError_t e = hipEventRecord(h->slots[i].done, h->slots[i].stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->slots[i].done, 0);
+    if (e != hipSuccess && rc == OSD_OK) { set_error("join failed: %s", hipGetErrorString(e)); rc = OSD_EHIP; }
+  }
+  if (rc != OSD_OK) return rc;
+  if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(h->stream));
+  return OSD_OK;
+}
+
+int osd_mixup(osd_handle* h, const float* data, const float* cond, const float* surv, const int64_t* perm, float lam, int64_t n,
+              float* data_out, float* cond_out, float* surv_out) {
+  if (!h) { set_error("null handle"); return OSD_EINVAL; }
+  OSD_TRY(check_rows(n));
+  if (!perm) { set_error("null perm"); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  if (data && data_out) OSD_HIP(launch_mixup(h->stream, data, perm, lam, n, h->arch.D, data_out));
+  if (cond && cond_out) OSD_HIP(launch_mixup(h->stream, cond, perm, lam, n, h->arch.cond_dim, cond_out));
+  if (surv && surv_out) OSD_HIP(launch_mixup(h->stream, surv, perm, lam, n, 1, surv_out));
+  return OSD_OK;
+}
+
+// ---- building blocks for the parity tests -----------------------------------------
+int osd_op_linear(osd_handle* h, const float* x, const float* w, const float* b, int64_t n, int K, int N, int silu, float* y) {
+  if (!h || !x || !w || !y) { set_error("null argument"); return OSD_EINVAL; }
+  OSD_TRY(check_rows(n));
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  GemmArgs g{};
+  g.A = w; g.lda = K; g.B0 = x; g.ldb0 = K; g.K0 = K; g.F = N; g.P = (int)n; g.K = K;
+  OSD_HIP(launch_linear(h->stream, g, true, true, b, y, N, silu != 0, false));
+  return OSD_OK;
+}
+
+int osd_op_linear_gn_silu(osd_handle* h, const float* x, int K1, const float* x2, int K2, const float* w, const float* b,
+                          const float* gamma, const float* beta, int64_t n, int N, float* y) {
+  if (!h || !x || !w || !b || !gamma || !beta || !y) { set_error("null argument"); return OSD_EINVAL; }
+  OSD_TRY(check_rows(n));
+  if (N % 8 || !gn_width_supported(N / 8)) { set_error("unsupported GroupNorm width %d", N / 8); return OSD_EUNSUPPORTED; }
+  if (K2 > 0 && (!x2 || K1 % 4)) { set_error("second panel needs x2 and K1 %% 4 == 0"); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  GemmArgs g{};
+  g.A = w; g.lda = K1 + K2; g.B0 = x; g.ldb0 = K1; g.K0 = K1; g.B1 = x2; g.ldb1 = K2; g.F = N; g.P = (int)n; g.K = K1 + K2;
+  GnArgs ga{};
+  ga.bias = b; ga.gamma = gamma; ga.beta = beta; ga.out = y; ga.ldo = N;
+  OSD_HIP(launch_gn_silu(h->stream, g, N / 8, ga));
+  return OSD_OK;
+}
+
+int osd_op_gemm(osd_handle* h, const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, int F, int P, int K, float* C,
+                int ldc, int accumulate) {
+  if (!h || !A || !B || !C) { set_error("null argument"); return OSD_EINVAL; }
+  if (F <= 0 || P <= 0 || K <= 0) { set_error("bad extents"); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.B0 = B; g.ldb0 = ldb; g.K0 = K; g.F = F; g.P = P; g.K = K;
+  hipError_t e = launch_linear(h->stream, g, a_kc != 0, b_kc != 0, nullptr, C, ldc, false, accumulate != 0);
+  if (e == hipErrorInvalidValue) { set_error("layout/accumulate combination not instantiated"); return OSD_EUNSUPPORTED; }
+  OSD_HIP(e);
+  return OSD_OK;
+}
+
+int osd_op_randn(osd_handle* h, float* out, int64_t rows, int cols, uint64_t seed, int64_t row_offset, uint32_t step, uint32_t kind) {
+  if (!h || !out) { set_error("null argument"); return OSD_EINVAL; }
+  OSD_TRY(check_rows(rows));
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  const uint32_t tag = kind == 0 ? (uint32_t)TAG_POSTERIOR : kind == 1 ? (uint32_t)TAG_QNOISE : (uint32_t)TAG_USER + (kind & 0xffu);
+  OSD_HIP(launch_fill_randn(h->stream, out, cols, rows, cols, seed, (uint32_t)row_offset, step, tag));
+  return OSD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,26 @@
+// fwd.h -- forward-pass plumbing shared by api.hip and train.hip.
+#pragma once
+#include "handle.h"
+#include "gemm.h"
+
+namespace osd {
+
+struct TrunkIn {
+  const float* x; int ldx; int64_t n;
+  const int* t_index;            // per-row t (training) or null
+  const int* t_dev; int t_imm;   // shared t: device counter (sampling chain) or immediate
+  bool train;                    // dropout active
+  bool save;                     // keep pre-norm activations + GroupNorm statistics for backward
+  const float* const* masks;     // injected keep-masks per block, or null -> Philox
+  uint64_t seed; uint32_t row_offset; uint32_t drop_step; const int* drop_step_dev;
+};
+
+int ensure_arena(Slot* s, int64_t floats);
+int64_t carve_fwd(const Arch& a, float* base, int64_t n, bool train, FwdWs* ws);
+int run_cond(osd_handle* h, hipStream_t s, const float* cond, int64_t n, const FwdWs& ws);
+int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in);
+GemmArgs output_proj_args(osd_handle* h, const FwdWs& ws, int64_t n);
+int check_ready(osd_handle* h);
+int check_rows(int64_t n);
+
+}  // namespace osd

@@ -1,0 +1,239 @@
+// gemm.h -- fp32 MFMA tile GEMM for gfx950 with fused epilogues.
+//
+//   out[p][f] (+)= epilogue( sum_k A(f,k) * B(p,k) )
+//
+// "f" (feature) is the MFMA M index and lands in the accumulator REGISTERS, "p"
+// (patient / batch row) is the MFMA N index and lands on the LANES.  With
+// v_mfma_f32_32x32x2_f32 a lane therefore holds, for ONE patient, 16 features of a
+// 32-feature block, 4 consecutive features per register quad.  That orientation makes
+//   * per-row GroupNorm statistics a register sum plus one lane^32 exchange, and
+//   * the output store a float4 per register quad into row-major [p][f],
+// which is what every epilogue here relies on.
+//
+// Operand storage:  KC  = [row][k]  (k contiguous:  Linear weights W[out][in], activations
+//                                    X[m][k], upstream gradients dY[m][n] for dgrad)
+//                   NKC = [k][row]  (row contiguous: W[n][k] read as A(k_feat, n) for dgrad,
+//                                    X[m][k] / dY[m][n] reduced over m for wgrad)
+// LDS images: KC tile [R][BK+4] read with ds_read_b128 (conflict-free at the +4 pad),
+//             NKC tile [BK][R] read with ds_read_b32 (lanes walk consecutive addresses).
+// The k order inside a BK=32 step is permuted identically for A and B (lane half h of
+// read i covers k = 8i+4h..8i+4h+3), which leaves the sum unchanged.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace osd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;
+constexpr int NTHREADS = 256;
+
+struct GemmArgs {
+  const float* A;  int lda;
+  const float* B0; int ldb0;
+  const float* B1; int ldb1;   // second K panel of a KC B operand (k >= K0); unused when K0 >= K
+  int K0;
+  int F, P, K;
+};
+
+template <int BF_, int BP_, int WF_, int WP_>
+struct Tile {
+  static constexpr int BF = BF_, BP = BP_, WF = WF_, WP = WP_;
+  static constexpr int NWF = BF / WF, NWP = BP / WP;
+  static constexpr int NFB = WF / 32, NPB = WP / 32;
+  static_assert(NWF * NWP == 4, "4 waves per workgroup");
+  static_assert(WF % 32 == 0 && WP % 32 == 0, "wave tile in 32x32 MFMA blocks");
+  static constexpr int A_ELEMS = BF * LDK;   // >= BK*BF (NKC image)
+  static constexpr int B_ELEMS = BP * LDK;
+  static constexpr int LDS_BYTES = 2 * (A_ELEMS + B_ELEMS) * 4;
+};
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// guarded 4-element load of v[i..i+3] from an array of n elements
+__device__ __forceinline__ float4 ld4g(const float* v, int i, int n) {
+  const float* p = v + i;
+  if (i + 3 < n && aligned16(p)) return *reinterpret_cast<const float4*>(p);
+  float4 r;
+  r.x = (i < n) ? p[0] : 0.f;
+  r.y = (i + 1 < n) ? p[1] : 0.f;
+  r.z = (i + 2 < n) ? p[2] : 0.f;
+  r.w = (i + 3 < n) ? p[3] : 0.f;
+  return r;
+}
+// guarded 4-element store to row[i..i+3], row has n valid elements
+__device__ __forceinline__ void st4g(float* row, int i, int n, float4 v) {
+  float* p = row + i;
+  if (i + 3 < n && aligned16(p)) { *reinterpret_cast<float4*>(p) = v; return; }
+  if (i < n) p[0] = v.x;
+  if (i + 1 < n) p[1] = v.y;
+  if (i + 2 < n) p[2] = v.z;
+  if (i + 3 < n) p[3] = v.w;
+}
+
+// ---- global -> register staging of one BK-deep tile ------------------------------
+// KC operand, R rows: thread owns k-chunk kc = tid&7 of rows (tid>>3) + 32*i.
+template <int R>
+struct StageKC {
+  static constexpr int N = R / 32;
+  float4 v[N];
+  __device__ __forceinline__ void load(const GemmArgs& g, bool isB, int r0, int nrows, int k0, int tid) {
+    const int kc = tid & 7;
+    int k = k0 + 4 * kc;
+    const float* base; int ld; int kend;
+    if (isB) {
+      if (k < g.K0) { base = g.B0; ld = g.ldb0; kend = (g.K0 < g.K ? g.K0 : g.K); }
+      else { base = g.B1; ld = g.ldb1; kend = g.K - g.K0; k -= g.K0; }
+    } else { base = g.A; ld = g.lda; kend = g.K; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int row = r0 + (tid >> 3) + 32 * i;
+      if (row < nrows && k < kend) v[i] = ld4g(base + (size_t)row * ld, k, kend);
+      else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void store(float* lds, int tid) const {
+    const int kc = tid & 7;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      *reinterpret_cast<float4*>(&lds[((tid >> 3) + 32 * i) * LDK + 4 * kc]) = v[i];
+  }
+};
+// NKC operand, tile [BK][R]: chunk c = tid + 256*i -> k = c / (R/4), rc = c % (R/4).
+template <int R>
+struct StageNK {
+  static constexpr int CPR = R / 4;
+  static constexpr int N = (BK * CPR) / NTHREADS;
+  static_assert(N >= 1, "tile too small");
+  float4 v[N];
+  __device__ __forceinline__ void load(const float* base, int ld, int r0, int nrows, int k0, int K, int tid) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int c = tid + NTHREADS * i;
+      const int k = k0 + c / CPR;
+      const int r = r0 + 4 * (c % CPR);
+      if (k < K && r < nrows) v[i] = ld4g(base + (size_t)k * ld, r, nrows);
+      else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int c = tid + NTHREADS * i;
+      *reinterpret_cast<float4*>(&lds[(c / CPR) * R + 4 * (c % CPR)]) = v[i];
+    }
+  }
+};
+
+// ---- the kernel -----------------------------------------------------------------
+// Epi::apply(acc, args, f_wave, p_wave, lane, F, P) consumes the wave's accumulators.
+template <class T, bool AKC, bool BKC, class Epi>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g, typename Epi::Args ea) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As0 = smem;
+  float* As1 = smem + T::A_ELEMS;
+  float* Bs0 = smem + 2 * T::A_ELEMS;
+  float* Bs1 = smem + 2 * T::A_ELEMS + T::B_ELEMS;
+
+  // XCD-aware tile order: blocks b, b+8, b+16 ... share an XCD (and its L2); give them
+  // the feature tiles of ONE patient tile so the activation panel is fetched once per XCD.
+  const int nft = (g.F + T::BF - 1) / T::BF;
+  const int npt = (g.P + T::BP - 1) / T::BP;
+  const int b = blockIdx.x;
+  const int idx = b >> 3;
+  const int ft = idx % nft;
+  const int pt = (idx / nft) * 8 + (b & 7);
+  if (pt >= npt) return;
+  const int f0 = ft * T::BF, p0 = pt * T::BP;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wf = (wave / T::NWP) * T::WF;   // wave's feature offset inside the block tile
+  const int wp = (wave % T::NWP) * T::WP;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  f32x16 acc[T::NFB][T::NPB];
+#pragma unroll
+  for (int i = 0; i < T::NFB; ++i)
+#pragma unroll
+    for (int j = 0; j < T::NPB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  StageKC<T::BF> sAk; StageNK<T::BF> sAn;
+  StageKC<T::BP> sBk; StageNK<T::BP> sBn;
+
+  auto gload = [&](int k0) {
+    if constexpr (AKC) sAk.load(g, false, f0, g.F, k0, tid);
+    else sAn.load(g.A, g.lda, f0, g.F, k0, g.K, tid);
+    if constexpr (BKC) sBk.load(g, true, p0, g.P, k0, tid);
+    else sBn.load(g.B0, g.ldb0, p0, g.P, k0, g.K, tid);
+  };
+  auto lstore = [&](float* As, float* Bs) {
+    if constexpr (AKC) sAk.store(As, tid); else sAn.store(As, tid);
+    if constexpr (BKC) sBk.store(Bs, tid); else sBn.store(Bs, tid);
+  };
+  auto compute = [&](const float* As, const float* Bs) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a[T::NFB][4], bb[T::NPB][4];
+#pragma unroll
+      for (int fb = 0; fb < T::NFB; ++fb) {
+        if constexpr (AKC) {
+          const float4 t = *reinterpret_cast<const float4*>(&As[(wf + 32 * fb + l31) * LDK + 8 * i + 4 * h]);
+          a[fb][0] = t.x; a[fb][1] = t.y; a[fb][2] = t.z; a[fb][3] = t.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[fb][e] = As[(8 * i + 4 * h + e) * T::BF + wf + 32 * fb + l31];
+        }
+      }
+#pragma unroll
+      for (int pb = 0; pb < T::NPB; ++pb) {
+        if constexpr (BKC) {
+          const float4 t = *reinterpret_cast<const float4*>(&Bs[(wp + 32 * pb + l31) * LDK + 8 * i + 4 * h]);
+          bb[pb][0] = t.x; bb[pb][1] = t.y; bb[pb][2] = t.z; bb[pb][3] = t.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bb[pb][e] = Bs[(8 * i + 4 * h + e) * T::BP + wp + 32 * pb + l31];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int fb = 0; fb < T::NFB; ++fb)
+#pragma unroll
+          for (int pb = 0; pb < T::NPB; ++pb)
+            acc[fb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fb][e], bb[pb][e], acc[fb][pb], 0, 0, 0);
+    }
+  };
+
+  const int nk = (g.K + BK - 1) / BK;
+  gload(0);
+  lstore(As0, Bs0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + 1 < nk);
+    float* Ac = (kt & 1) ? As1 : As0;
+    float* Bc = (kt & 1) ? Bs1 : Bs0;
+    float* An = (kt & 1) ? As0 : As1;
+    float* Bn = (kt & 1) ? Bs0 : Bs1;
+    if (more) gload((kt + 1) * BK);
+    compute(Ac, Bc);
+    if (more) lstore(An, Bn);
+    __syncthreads();
+  }
+
+  Epi::template apply<T::NFB, T::NPB>(acc, ea, f0 + wf, p0 + wp, lane, g.F, g.P);
+}
+
+// element (fb, reg) of a lane's fragment is feature  f_wave + 32*fb + 8*(reg>>2) + 4*h + (reg&3)
+// and patient p_wave + 32*pb + (lane&31).
+#define OSD_FOR_QUADS(fb, pb, q)                         \
+  _Pragma("unroll") for (int fb = 0; fb < NFB; ++fb)     \
+  _Pragma("unroll") for (int pb = 0; pb < NPB; ++pb)     \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q)
+
+}  // namespace osd

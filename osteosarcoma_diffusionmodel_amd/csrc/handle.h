@@ -1,0 +1,102 @@
+// handle.h -- host-side state behind osd_handle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/osdiff.h"
+
+namespace osd {
+
+void set_error(const char* fmt, ...);
+
+#define OSD_HIP(call)                                                                    \
+  do {                                                                                   \
+    hipError_t e__ = (call);                                                             \
+    if (e__ != hipSuccess) {                                                             \
+      ::osd::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return OSD_EHIP;                                                                   \
+    }                                                                                    \
+  } while (0)
+
+#define OSD_TRY(call)               \
+  do {                              \
+    int r__ = (call);               \
+    if (r__ != OSD_OK) return r__;  \
+  } while (0)
+
+// One Linear of the denoiser trunk (with or without GroupNorm+SiLU behind it).
+struct LayerDesc {
+  int K1, K2;          // input panel widths (K2 > 0: concat-free decoder input)
+  int N;               // output width
+  int w, b;            // parameter indices
+  int gamma, beta;     // -1 when no GroupNorm
+  int gw;              // channels per group (N/8) when GroupNorm
+  int block;           // block index (execution order) or -1
+  int half;            // 0 first Linear of the block (dropout behind it), 1 second
+};
+
+// Parameter indices in named_parameters() order.
+struct ParamMap {
+  int ce0_w, ce0_b, ce2_w, ce2_b;
+  int in_w, in_b, cp_w, cp_b, tp_w, tp_b;
+  int out_w, out_b;
+  int n_params;
+  std::vector<int64_t> numel;
+};
+
+struct Arch {
+  int D, H0, cond_dim, time_dim, cond_width, T;
+  int n_blocks, n_enc;
+  std::vector<int> hidden;
+  std::vector<LayerDesc> layers;   // 2 per block, execution order
+  std::vector<int> block_out;      // output width of block i
+  ParamMap pm;
+  int64_t act_floats_per_row;      // forward workspace per row
+};
+
+int build_arch(const osd_config& cfg, Arch* a);
+
+// Forward activations of one row chunk (all device pointers into one arena).
+struct FwdWs {
+  float* ce1;     // [n][64]   SiLU(Linear(cond))
+  float* ce2;     // [n][64]   condition embedding
+  float* cproj;   // [n][H0]
+  float* h0;      // [n][H0]
+  std::vector<float*> mid;   // per block: first-half output (post dropout)  [n][C]
+  std::vector<float*> out;   // per block: block output                      [n][C]
+  // training extras (null in inference)
+  std::vector<float*> z1, z2;        // pre-norm activations of both halves
+  std::vector<float*> st1, st2;      // (mean, rstd) [n][8][2]
+};
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  float* arena = nullptr;
+  int64_t arena_floats = 0;
+  int* t_dev = nullptr;
+  hipGraph_t graph = nullptr;        // graph of the last captured reverse step (kept alive
+  hipGraphExec_t exec = nullptr;     // until its replays have drained)
+};
+
+}  // namespace osd
+
+struct osd_handle {
+  osd_config cfg;
+  osd::Arch arch;
+  hipStream_t stream = nullptr;
+  std::vector<const float*> params;
+  bool have_schedule = false, have_weights = false;
+  float *d_sqrt_ac = nullptr, *d_sqrt_1m = nullptr, *d_coef = nullptr, *d_time_emb = nullptr, *d_temb = nullptr;
+  int64_t chunk_rows = 32768;
+  int n_streams = 2;
+  std::vector<osd::Slot> slots;
+  osd::Slot main;            // workspace used by the single-stream entry points
+  hipEvent_t fork_ev = nullptr;
+  // training workspace
+  float* train_arena = nullptr;
+  int64_t train_arena_floats = 0;
+  float* loss_dev = nullptr;
+  double* normsq_dev = nullptr;
+};

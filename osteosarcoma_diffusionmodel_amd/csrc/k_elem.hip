@@ -1,0 +1,135 @@
+// k_elem.hip -- HBM-bound elementwise kernels: Philox fills, q_sample, mixup, copies.
+#include "kernels.h"
+
+namespace osd {
+
+__global__ void k_set_int(int* p, int v) { *p = v; }
+__global__ void k_add_int(int* p, int d) { *p += d; }
+hipError_t launch_set_int(hipStream_t s, int* p, int v) { hipLaunchKernelGGL(k_set_int, 1, 1, 0, s, p, v); return hipGetLastError(); }
+hipError_t launch_add_int(hipStream_t s, int* p, int d) { hipLaunchKernelGGL(k_add_int, 1, 1, 0, s, p, d); return hipGetLastError(); }
+
+static inline int ew_grid(int64_t work) {
+  int64_t b = (work + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// one thread per (row, 4 columns)
+__global__ void k_fill_randn(float* out, int ld, int64_t rows, int cols, uint64_t seed, uint32_t row_offset, uint32_t step, uint32_t tag) {
+  const int c4n = (cols + 3) >> 2;
+  const int64_t total = rows * c4n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4n;
+    const int c4 = (int)(i - r * c4n);
+    const float4 n = randn4(seed, row_offset + (uint32_t)r, (uint32_t)c4, step, tag);
+    st4g(out + r * ld, 4 * c4, cols, n);
+  }
+}
+hipError_t launch_fill_randn(hipStream_t s, float* out, int ld, int64_t rows, int cols, uint64_t seed, uint32_t row_offset, uint32_t step, uint32_t tag) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_fill_randn, ew_grid(rows * ((cols + 3) / 4)), 256, 0, s, out, ld, rows, cols, seed, row_offset, step, tag);
+  return hipGetLastError();
+}
+
+__global__ void k_copy2d(const float* src, int lds, float* dst, int ldd, int64_t rows, int cols) {
+  const int c4n = (cols + 3) >> 2;
+  const int64_t total = rows * c4n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4n;
+    const int c = 4 * (int)(i - r * c4n);
+    st4g(dst + r * ldd, c, cols, ld4g(src + r * lds, c, cols));
+  }
+}
+hipError_t launch_copy2d(hipStream_t s, const float* src, int lds, float* dst, int ldd, int64_t rows, int cols) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_copy2d, ew_grid(rows * ((cols + 3) / 4)), 256, 0, s, src, lds, dst, ldd, rows, cols);
+  return hipGetLastError();
+}
+
+// q_sample (models/diffusion.py:337-340): x_t = sqrt_ac[t]*x0 + sqrt_1m[t]*eps, two roundings of the
+// products then one add, as torch evaluates it.
+__global__ void k_q_sample(const float* x0, const int* t, const float* sqrt_ac, const float* sqrt_1m, const float* noise_in,
+                           int64_t rows, int cols, uint64_t seed, uint32_t row_offset, float* x_t, float* noise_out) {
+  const int c4n = (cols + 3) >> 2;
+  const int64_t total = rows * c4n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4n;
+    const int c = 4 * (int)(i - r * c4n);
+    const int tt = t[r];
+    const float a = sqrt_ac[tt], b = sqrt_1m[tt];
+    const float4 x = ld4g(x0 + r * cols, c, cols);
+    float4 n;
+    if (noise_in) n = ld4g(noise_in + r * cols, c, cols);
+    else n = randn4(seed, row_offset + (uint32_t)r, (uint32_t)(c >> 2), 0u, TAG_QNOISE);
+    float4 o;
+    o.x = __fadd_rn(__fmul_rn(a, x.x), __fmul_rn(b, n.x));
+    o.y = __fadd_rn(__fmul_rn(a, x.y), __fmul_rn(b, n.y));
+    o.z = __fadd_rn(__fmul_rn(a, x.z), __fmul_rn(b, n.z));
+    o.w = __fadd_rn(__fmul_rn(a, x.w), __fmul_rn(b, n.w));
+    st4g(x_t + r * cols, c, cols, o);
+    if (noise_out && noise_out != noise_in) st4g(noise_out + r * cols, c, cols, n);
+  }
+}
+hipError_t launch_q_sample(hipStream_t s, const float* x0, const int* t, const float* sqrt_ac, const float* sqrt_1m,
+                           const float* noise_in, int64_t rows, int cols, uint64_t seed, uint32_t row_offset,
+                           float* x_t, float* noise_out) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_q_sample, ew_grid(rows * ((cols + 3) / 4)), 256, 0, s, x0, t, sqrt_ac, sqrt_1m, noise_in, rows, cols, seed,
+                     row_offset, x_t, noise_out);
+  return hipGetLastError();
+}
+
+// torch.randint(0, T, (B,)) stand-in (models/diffusion.py:361): uniform ints from Philox.
+__global__ void k_randint(int* out, int64_t n, int hi, uint64_t seed, uint32_t row_offset) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 r = philox_at(seed, row_offset + (uint32_t)i, 0u, 0u, TAG_TSTEP);
+    out[i] = (int)(((uint64_t)r.x * (uint64_t)hi) >> 32);
+  }
+}
+hipError_t launch_randint(hipStream_t s, int* out, int64_t n, int hi, uint64_t seed, uint32_t row_offset) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_randint, ew_grid(n), 256, 0, s, out, n, hi, seed, row_offset);
+  return hipGetLastError();
+}
+
+// mixup (utils/train.py:117-119): lam*v + (1-lam)*v[perm], products rounded separately.
+__global__ void k_mixup(const float* v, const int64_t* perm, float lam, float oml, int64_t rows, int cols, float* out) {
+  const int c4n = (cols + 3) >> 2;
+  const int64_t total = rows * c4n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4n;
+    const int c = 4 * (int)(i - r * c4n);
+    const float4 a = ld4g(v + r * cols, c, cols);
+    const float4 b = ld4g(v + perm[r] * cols, c, cols);
+    float4 o;
+    o.x = __fadd_rn(__fmul_rn(lam, a.x), __fmul_rn(oml, b.x));
+    o.y = __fadd_rn(__fmul_rn(lam, a.y), __fmul_rn(oml, b.y));
+    o.z = __fadd_rn(__fmul_rn(lam, a.z), __fmul_rn(oml, b.z));
+    o.w = __fadd_rn(__fmul_rn(lam, a.w), __fmul_rn(oml, b.w));
+    st4g(out + r * cols, c, cols, o);
+  }
+}
+hipError_t launch_mixup(hipStream_t s, const float* v, const int64_t* perm, float lam, int64_t rows, int cols, float* out) {
+  if (rows <= 0) return hipSuccess;
+  // python: lam and (1 - lam) are float64 scalars; torch multiplies an fp32 tensor by each as fp32
+  const float oml = (float)(1.0 - (double)lam);
+  hipLaunchKernelGGL(k_mixup, ew_grid(rows * ((cols + 3) / 4)), 256, 0, s, v, perm, lam, oml, rows, cols, out);
+  return hipGetLastError();
+}
+
+__global__ void k_threshold(const float* x, int ldx, int64_t rows, int cols, float thr, float* out) {
+  const int64_t total = rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    out[i] = (x[r * ldx + c] > thr) ? 1.0f : 0.0f;
+  }
+}
+hipError_t launch_threshold(hipStream_t s, const float* x, int ldx, int64_t rows, int cols, float thr, float* out) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_threshold, ew_grid(rows * cols), 256, 0, s, x, ldx, rows, cols, thr, out);
+  return hipGetLastError();
+}
+
+}  // namespace osd

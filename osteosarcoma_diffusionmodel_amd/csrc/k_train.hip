@@ -1,0 +1,253 @@
+// k_train.hip -- HBM-bound kernels of the backward pass and the optimizer:
+// GroupNorm+SiLU(+dropout) backward with per-row wavefront reductions, column sums,
+// the time-embedding scatter, clip_grad_norm_ + AdamW over a flat buffer.
+#include "kernels_train.h"
+#include "gemm.h"
+#include "rng.h"
+
+namespace osd {
+
+static inline int ew_grid(int64_t work, int per_block = 256) {
+  int64_t b = (work + per_block - 1) / per_block;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---- zero several small buffers in one launch --------------------------------------
+__global__ void k_zero_many(ZeroList zl) {
+  const int i = blockIdx.y;
+  float* p = zl.ptr[i];
+  const int64_t n = zl.count[i];
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) p[j] = 0.f;
+}
+hipError_t launch_zero_many(hipStream_t s, const ZeroList& zl) {
+  if (zl.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_zero_many, dim3(64, zl.n), 256, 0, s, zl);
+  return hipGetLastError();
+}
+
+// ---- SiLU forward / backward on a dense [n][c] buffer ---------------------------------
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void k_silu_fwd(const float* u, float* y, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = u[i];
+    y[i] = x / (1.0f + expf(-x));
+  }
+}
+hipError_t launch_silu_fwd(hipStream_t s, const float* u, float* y, int64_t total) {
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_silu_fwd, ew_grid(total), 256, 0, s, u, y, total);
+  return hipGetLastError();
+}
+__global__ void k_silu_bwd(const float* u, const float* g, float* gu, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = u[i];
+    const float sg = sigmoid_f(x);
+    gu[i] = g[i] * (sg * (1.0f + x * (1.0f - sg)));
+  }
+}
+hipError_t launch_silu_bwd(hipStream_t s, const float* u, const float* g, float* gu, int64_t total) {
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_silu_bwd, ew_grid(total), 256, 0, s, u, g, gu, total);
+  return hipGetLastError();
+}
+
+// ---- column sums: out[c] += sum_r in[r][c]   (out zeroed by the caller) --------------------
+__global__ void k_colsum(const float* in, int ld, int64_t rows, int cols, int rows_per_block, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int64_t r = r0; r < r1; ++r) s += in[r * ld + c];
+  atomicAdd(out + c, s);
+}
+hipError_t launch_colsum(hipStream_t s, const float* in, int ld, int64_t rows, int cols, float* out) {
+  if (rows <= 0 || cols <= 0) return hipSuccess;
+  const int rpb = 64;
+  dim3 grid((cols + 255) / 256, (unsigned)((rows + rpb - 1) / rpb));
+  hipLaunchKernelGGL(k_colsum, grid, 256, 0, s, in, ld, rows, cols, rpb, out);
+  return hipGetLastError();
+}
+
+// ---- time embedding: g_table[t[r]][c] += g[r][c]   (table zeroed by the caller) -------------
+__global__ void k_scatter_rows(const float* g, const int* t, int64_t rows, int cols, float* table) {
+  const int64_t total = rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    atomicAdd(table + (int64_t)t[r] * cols + c, g[i]);
+  }
+}
+hipError_t launch_scatter_rows(hipStream_t s, const float* g, const int* t, int64_t rows, int cols, float* table) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_scatter_rows, ew_grid(rows * cols), 256, 0, s, g, t, rows, cols, table);
+  return hipGetLastError();
+}
+
+// ---- GroupNorm(8) + SiLU (+ dropout) backward ------------------------------------------------
+// One wave per row at a time; lane l owns columns 4l + 256j.. (float4), so the GW/4 lanes of a
+// group are adjacent and the two per-group means are a __shfl_xor butterfly.  Per-column sums
+// (d gamma, d beta, d bias) accumulate in registers over the wave's rows, then one atomic each.
+//   y = zhat*gamma + beta, a = silu(y), out = a * keep
+//   g_y = g*keep*silu'(y);  g_zhat = g_y*gamma
+//   g_z = rstd * (g_zhat - mean_g(g_zhat) - zhat*mean_g(g_zhat*zhat))
+template <int GW, int NJ>
+__global__ __launch_bounds__(256) void k_gn_silu_bwd(GnBwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int C = a.C;
+  float acc_g[NJ][4], acc_b[NJ][4], acc_z[NJ][4];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc_g[j][e] = acc_b[j][e] = acc_z[j][e] = 0.f;
+  float4 gam[NJ], bet[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = 4 * lane + 256 * j;
+    gam[j] = ld4g(a.gamma, c, C);
+    bet[j] = ld4g(a.beta, c, C);
+  }
+  for (int64_t r = wave; r < a.rows; r += nwaves) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = 4 * lane + 256 * j;
+      const bool in = c < C;
+      const float4 g4 = in ? ld4g(a.g + r * C, c, C) : make_float4(0, 0, 0, 0);
+      const float4 z4 = in ? ld4g(a.z + r * C, c, C) : make_float4(0, 0, 0, 0);
+      float mean = 0.f, rstd = 0.f;
+      if (in) { const float* sp = a.stats + (r * (C / GW) + c / GW) * 2; mean = sp[0]; rstd = sp[1]; }
+      float keep[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.drop_mode == 1 && in) {
+        const float4 m4 = ld4g(a.mask + r * C, c, C);
+        keep[0] = m4.x * a.keep_scale; keep[1] = m4.y * a.keep_scale; keep[2] = m4.z * a.keep_scale; keep[3] = m4.w * a.keep_scale;
+      } else if (a.drop_mode == 2 && in) {
+        const uint4 rr = philox_at(a.seed, a.row_offset + (uint32_t)r, (uint32_t)(c >> 2), a.step, a.tag);
+        keep[0] = (u01(rr.x) >= a.p_drop) ? a.keep_scale : 0.f;
+        keep[1] = (u01(rr.y) >= a.p_drop) ? a.keep_scale : 0.f;
+        keep[2] = (u01(rr.z) >= a.p_drop) ? a.keep_scale : 0.f;
+        keep[3] = (u01(rr.w) >= a.p_drop) ? a.keep_scale : 0.f;
+      }
+      const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+      const float zv[4] = {z4.x, z4.y, z4.z, z4.w};
+      const float gm[4] = {gam[j].x, gam[j].y, gam[j].z, gam[j].w};
+      const float bt[4] = {bet[j].x, bet[j].y, bet[j].z, bet[j].w};
+      float zh[4], gzh[4];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        zh[e] = (zv[e] - mean) * rstd;
+        const float y = zh[e] * gm[e] + bt[e];
+        const float sg = sigmoid_f(y);
+        const float gy = gv[e] * keep[e] * (sg * (1.0f + y * (1.0f - sg)));
+        acc_g[j][e] += gy * zh[e];
+        acc_b[j][e] += gy;
+        gzh[e] = gy * gm[e];
+        s1 += gzh[e];
+        s2 += gzh[e] * zh[e];
+      }
+#pragma unroll
+      for (int o = 1; o < GW / 4; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      const float m1 = s1 * (1.0f / GW), m2 = s2 * (1.0f / GW);
+      float gz[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gz[e] = rstd * (gzh[e] - m1 - zh[e] * m2); acc_z[j][e] += gz[e]; }
+      if (in) st4g(a.gz + r * C, c, C, make_float4(gz[0], gz[1], gz[2], gz[3]));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 4 * lane + 256 * j + e;
+      if (c < C) {
+        atomicAdd(a.dgamma + c, acc_g[j][e]);
+        atomicAdd(a.dbeta + c, acc_b[j][e]);
+        atomicAdd(a.dbias + c, acc_z[j][e]);
+      }
+    }
+}
+
+template <int GW>
+static hipError_t gn_bwd_go(hipStream_t s, const GnBwdArgs& a) {
+  const int nj = (a.C + 255) / 256;
+  int blocks = (int)((a.rows + 15) / 16);      // ~4 rows per wave
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  switch (nj) {
+    case 1: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 1>), blocks, 256, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 2>), blocks, 256, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 3>), blocks, 256, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 4>), blocks, 256, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_gn_silu_bwd(hipStream_t s, int gw, const GnBwdArgs& a) {
+  if (a.rows <= 0) return hipSuccess;
+  switch (gw) {
+    case 4: return gn_bwd_go<4>(s, a);
+    case 8: return gn_bwd_go<8>(s, a);
+    case 16: return gn_bwd_go<16>(s, a);
+    case 32: return gn_bwd_go<32>(s, a);
+    case 64: return gn_bwd_go<64>(s, a);
+    case 128: return gn_bwd_go<128>(s, a);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ---- clip_grad_norm_ + AdamW over flat buffers -----------------------------------------------
+__global__ void k_sumsq(const float* g, int64_t n, double* out) {
+  double s = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = g[i];
+    s += (double)v * (double)v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ double part[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) part[w] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ void k_adamw(float* p, float* g, float* m, float* v, int64_t n, AdamArgs a, const double* normsq, float* norm_out) {
+  float coef = 1.0f;
+  const float norm = (float)sqrt(*normsq);
+  if (a.max_norm > 0.f) {
+    coef = a.max_norm / (norm + 1e-6f);
+    if (coef > 1.0f) coef = 1.0f;
+  }
+  if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = norm;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    if (a.max_norm > 0.f) { gi = __fmul_rn(gi, coef); g[i] = gi; }     // clip_grad_norm_ scales the grads in place
+    float pi = __fmul_rn(p[i], a.decay);                                 // p.mul_(1 - lr*wd)
+    float mi = m[i];
+    mi = __fadd_rn(mi, __fmul_rn(a.one_minus_b1, __fsub_rn(gi, mi)));    // exp_avg.lerp_(g, 1-b1)
+    float vi = __fmul_rn(v[i], a.b2);
+    vi = __fadd_rn(vi, __fmul_rn(__fmul_rn(a.one_minus_b2, gi), gi));    // mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = __fadd_rn(__fdiv_rn(sqrtf(vi), a.bc2_sqrt), a.eps);
+    pi = __fadd_rn(pi, __fmul_rn(a.neg_step_size, __fdiv_rn(mi, denom)));   // addcdiv_(m, denom, -lr/bc1)
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+hipError_t launch_clip_adamw(hipStream_t s, float* p, float* g, float* m, float* v, int64_t n, const AdamArgs& a, double* normsq_ws,
+                             float* norm_out) {
+  if (n <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(normsq_ws, 0, sizeof(double), s);
+  if (e != hipSuccess) return e;
+  const int grid = ew_grid(n, 256 * 8);
+  hipLaunchKernelGGL(k_sumsq, grid, 256, 0, s, g, n, normsq_ws);
+  hipLaunchKernelGGL(k_adamw, ew_grid(n, 256 * 4), 256, 0, s, p, g, m, v, n, a, normsq_ws, norm_out);
+  return hipGetLastError();
+}
+
+}  // namespace osd

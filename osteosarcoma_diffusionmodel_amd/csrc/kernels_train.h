@@ -1,0 +1,38 @@
+// kernels_train.h -- wrappers of the backward / optimizer kernels (k_train.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace osd {
+
+struct ZeroList { float* ptr[128]; int64_t count[128]; int n; };
+hipError_t launch_zero_many(hipStream_t s, const ZeroList& zl);
+
+hipError_t launch_silu_fwd(hipStream_t s, const float* u, float* y, int64_t total);
+hipError_t launch_silu_bwd(hipStream_t s, const float* u, const float* g, float* gu, int64_t total);
+hipError_t launch_colsum(hipStream_t s, const float* in, int ld, int64_t rows, int cols, float* out);
+hipError_t launch_scatter_rows(hipStream_t s, const float* g, const int* t, int64_t rows, int cols, float* table);
+
+struct GnBwdArgs {
+  const float* g;        // dL/d(output of the half block) [rows][C]
+  const float* z;        // pre-norm activations           [rows][C]
+  const float* stats;    // (mean, rstd)                   [rows][8][2]
+  const float* gamma; const float* beta;
+  float* gz;             // dL/dz                          [rows][C]
+  float* dgamma; float* dbeta; float* dbias;   // [C], accumulated atomically (zeroed by the caller)
+  int64_t rows; int C;
+  int drop_mode; const float* mask; float keep_scale; float p_drop;
+  uint64_t seed; uint32_t row_offset; uint32_t step; uint32_t tag;
+};
+hipError_t launch_gn_silu_bwd(hipStream_t s, int gw, const GnBwdArgs& a);
+
+struct AdamArgs {
+  float decay;          // 1 - lr*wd
+  float one_minus_b1, b2, one_minus_b2;
+  float bc2_sqrt, eps, neg_step_size;
+  float max_norm;
+};
+hipError_t launch_clip_adamw(hipStream_t s, float* p, float* g, float* m, float* v, int64_t n, const AdamArgs& a, double* normsq_ws,
+                             float* norm_out);
+
+}  // namespace osd

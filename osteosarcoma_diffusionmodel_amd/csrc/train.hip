@@ -1,0 +1,258 @@
+// train.hip -- training entry points of the C ABI (include/osdiff.h):
+// fused forward + backward of the eps-prediction MSE loss, mixup lives in api.hip,
+// clip_grad_norm_ + AdamW over flat buffers.
+#include <math.h>
+#include <algorithm>
+#include "handle.h"
+#include "kernels.h"
+#include "kernels_train.h"
+#include "fwd.h"
+
+namespace osd {
+
+static int64_t align_up64(int64_t v) { return (v + 63) / 64 * 64; }
+
+struct TrainWs {
+  FwdWs f;
+  float *x_t, *noise, *d_out, *u0;
+  int* t_idx;
+  float *g_h0, *g_ce2, *g_ce1, *g_u, *g_temb;
+  std::vector<float*> g_out, g_z2, g_mid, g_z1;
+  double* normsq;
+};
+
+static int64_t carve_train(const Arch& a, float* base, int64_t n, TrainWs* w) {
+  int64_t off = 0;
+  auto take = [&](int64_t floats) { float* p = base ? base + off : nullptr; off += align_up64(floats); return p; };
+  float* fbase = base;
+  const int64_t fwd = carve_fwd(a, fbase, n, true, &w->f);
+  off = align_up64(fwd);
+  w->x_t = take(n * a.D); w->noise = take(n * a.D); w->d_out = take(n * a.D);
+  w->u0 = take(n * 64);
+  w->t_idx = (int*)take(n);
+  w->g_h0 = take(n * a.H0); w->g_ce2 = take(n * 64); w->g_ce1 = take(n * 64); w->g_u = take(n * 64);
+  w->g_temb = take((int64_t)a.T * a.H0);
+  w->g_out.resize(a.n_blocks); w->g_z2.resize(a.n_blocks); w->g_mid.resize(a.n_blocks); w->g_z1.resize(a.n_blocks);
+  for (int b = 0; b < a.n_blocks; ++b) {
+    const int64_t c = a.block_out[b];
+    w->g_out[b] = take(n * c); w->g_z2[b] = take(n * c); w->g_mid[b] = take(n * c); w->g_z1[b] = take(n * c);
+  }
+  w->normsq = (double*)take(16);
+  return off;
+}
+
+// out[p][f] = sum_k A(f,k) B(p,k) helpers for the two backward GEMM shapes
+static hipError_t wgrad(hipStream_t s, const float* x, int ldx, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, int lddw) {
+  // dW[n_out][k_in] = sum_m gz[m][n_out] * x[m][k_in]
+  GemmArgs g{};
+  g.A = x; g.lda = ldx; g.B0 = gz; g.ldb0 = ldg; g.K0 = (int)rows; g.F = kin; g.P = nout; g.K = (int)rows;
+  return launch_linear(s, g, false, false, nullptr, dw, lddw, false, false);
+}
+static hipError_t dgrad(hipStream_t s, const float* w, int ldw, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dx, int lddx, bool accumulate) {
+  // dX[m][k_in] (+)= sum_n gz[m][n] * W[n][k_in]
+  GemmArgs g{};
+  g.A = w; g.lda = ldw; g.B0 = gz; g.ldb0 = ldg; g.K0 = nout; g.F = kin; g.P = (int)rows; g.K = nout;
+  return launch_linear(s, g, false, true, nullptr, dx, lddx, false, accumulate);
+}
+
+}  // namespace osd
+
+using namespace osd;
+
+extern "C" {
+
+int osd_grad_buckets(const osd_config* cfg, int32_t* first, int32_t* last, int max_buckets) {
+  if (!cfg) return 0;
+  Arch a;
+  if (build_arch(*cfg, &a) != OSD_OK) return 0;
+  // backward finalises: output_proj, then the blocks last-to-first, then everything before the blocks
+  std::vector<std::pair<int, int>> bk;
+  bk.push_back({a.pm.out_w, a.pm.out_b});
+  for (int b = a.n_blocks - 1; b >= 0; --b) bk.push_back({a.layers[2 * b].w, a.layers[2 * b + 1].beta});
+  bk.push_back({0, a.pm.tp_b});
+  const int n = (int)bk.size();
+  if (first && last)
+    for (int i = 0; i < n && i < max_buckets; ++i) { first[i] = bk[i].first; last[i] = bk[i].second; }
+  return n;
+}
+
+int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, int64_t n, const int32_t* t_index, const float* noise,
+                           const float* const* masks, uint64_t seed, int64_t row_offset, int flags, float* loss_out,
+                           float* const* grads, float loss_scale, void* const* events, int n_events) {
+  OSD_TRY(check_ready(h));
+  OSD_TRY(check_rows(n));
+  if (!x0 || !cond || !loss_out) { set_error("null tensor"); return OSD_EINVAL; }
+  if (n == 0) { set_error("empty batch"); return OSD_EINVAL; }
+  const Arch& a = h->arch;
+  const ParamMap& pm = a.pm;
+  const int n_buckets = a.n_blocks + 2;
+  if (events && n_events != n_buckets) { set_error("expected %d events (osd_grad_buckets), got %d", n_buckets, n_events); return OSD_EINVAL; }
+  if (grads)
+    for (int i = 0; i < pm.n_params; ++i)
+      if (!grads[i]) { set_error("grads[%d] is null", i); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  hipStream_t s = h->stream;
+  const bool train = (flags & OSD_F_TRAIN_MODE) != 0;
+  const bool drop = train && h->cfg.dropout_p > 0.f;
+  const int D = a.D;
+  const uint32_t roff = (uint32_t)row_offset;
+
+  TrainWs w;
+  const int64_t need = carve_train(a, nullptr, n, &w);
+  if (h->train_arena_floats < need) {
+    if (h->train_arena) { OSD_HIP(hipStreamSynchronize(s)); OSD_HIP(hipFree(h->train_arena)); h->train_arena = nullptr; h->train_arena_floats = 0; }
+    void* p = nullptr;
+    if (hipMalloc(&p, (size_t)need * 4) != hipSuccess) { set_error("hipMalloc of %lld bytes failed", (long long)need * 4); return OSD_ENOMEM; }
+    h->train_arena = (float*)p;
+    h->train_arena_floats = need;
+  }
+  carve_train(a, h->train_arena, n, &w);
+
+  // ---- zero everything that is accumulated atomically ----
+  {
+    ZeroList zl{};
+    auto add = [&](float* p, int64_t c) { zl.ptr[zl.n] = p; zl.count[zl.n] = c; ++zl.n; };
+    add(loss_out, 1);
+    if (grads) {
+      add(w.g_temb, (int64_t)a.T * a.H0);
+      const int small[] = {pm.ce0_b, pm.ce2_b, pm.in_b, pm.cp_b, pm.tp_b, pm.out_b};
+      for (int i : small) add(grads[i], pm.numel[i]);
+      for (const LayerDesc& l : a.layers) { add(grads[l.b], l.N); add(grads[l.gamma], l.N); add(grads[l.beta], l.N); }
+    }
+    if (zl.n > 128) { set_error("too many parameter tensors"); return OSD_EUNSUPPORTED; }
+    OSD_HIP(launch_zero_many(s, zl));
+  }
+
+  // ---- forward (models/diffusion.py:361-377) ----
+  // the t_emb table follows the current time_proj weights
+  {
+    GemmArgs g{};
+    g.A = h->params[pm.tp_w]; g.lda = a.time_dim; g.B0 = h->d_time_emb; g.ldb0 = a.time_dim; g.K0 = a.time_dim;
+    g.F = a.H0; g.P = a.T; g.K = a.time_dim;
+    OSD_HIP(launch_linear(s, g, true, true, h->params[pm.tp_b], h->d_temb, a.H0, false, false));
+  }
+  const int* t_idx = t_index;
+  if (!t_idx) { OSD_HIP(launch_randint(s, w.t_idx, n, a.T, seed, roff)); t_idx = w.t_idx; }
+  OSD_HIP(launch_q_sample(s, x0, t_idx, h->d_sqrt_ac, h->d_sqrt_1m, noise, n, D, seed, roff, w.x_t, w.noise));
+  const float* eps_true = noise ? noise : w.noise;
+  // ConditionalEmbedding with the pre-activation kept for backward
+  {
+    GemmArgs g{};
+    g.A = h->params[pm.ce0_w]; g.lda = a.cond_dim; g.B0 = cond; g.ldb0 = a.cond_dim; g.K0 = a.cond_dim; g.F = 64; g.P = (int)n; g.K = a.cond_dim;
+    OSD_HIP(launch_linear(s, g, true, true, h->params[pm.ce0_b], w.u0, 64, false, false));
+    OSD_HIP(launch_silu_fwd(s, w.u0, w.f.ce1, n * 64));
+    g.A = h->params[pm.ce2_w]; g.lda = 64; g.B0 = w.f.ce1; g.ldb0 = 64; g.K0 = 64; g.K = 64;
+    OSD_HIP(launch_linear(s, g, true, true, h->params[pm.ce2_b], w.f.ce2, 64, false, false));
+    g.A = h->params[pm.cp_w]; g.B0 = w.f.ce2; g.F = a.H0;
+    OSD_HIP(launch_linear(s, g, true, true, h->params[pm.cp_b], w.f.cproj, a.H0, false, false));
+  }
+  TrainWs& W = w;
+  TrunkIn in{};
+  in.x = W.x_t; in.ldx = D; in.n = n; in.t_index = t_idx; in.train = train; in.save = grads != nullptr;
+  in.masks = masks; in.seed = seed; in.row_offset = roff; in.drop_step = 0;
+  OSD_TRY(run_trunk(h, s, W.f, in));
+  const int last = a.n_blocks - 1;
+  const int Hl = a.block_out[last];
+  {
+    GemmArgs g = output_proj_args(h, W.f, n);
+    EpiMse::Args ea{};
+    ea.bias = h->params[pm.out_b]; ea.noise = eps_true; ea.ldn = D;
+    ea.dout = grads ? W.d_out : nullptr; ea.ldd = D; ea.pred = nullptr; ea.ldp = D; ea.loss = loss_out;
+    ea.inv_count = (float)(1.0 / ((double)n * (double)D));
+    ea.gscale = (float)(2.0 * (double)loss_scale / ((double)n * (double)D));
+    OSD_HIP(launch_mse(s, g, ea));
+  }
+  if (!grads) return OSD_OK;
+
+  // ---- backward ----
+  int ev = 0;
+  auto record = [&]() -> int {
+    if (events) OSD_HIP(hipEventRecord((hipEvent_t)events[ev], s));
+    ++ev;
+    return OSD_OK;
+  };
+  // output_proj
+  OSD_HIP(wgrad(s, W.f.out[last], Hl, Hl, W.d_out, D, D, n, grads[pm.out_w], Hl));
+  OSD_HIP(launch_colsum(s, W.d_out, D, n, D, grads[pm.out_b]));
+  OSD_TRY(record());
+  OSD_HIP(dgrad(s, h->params[pm.out_w], Hl, Hl, W.d_out, D, D, n, W.g_out[last], Hl, false));
+
+  const float keep_scale = (float)(1.0 / (1.0 - (double)h->cfg.dropout_p));
+  for (int b = a.n_blocks - 1; b >= 0; --b) {
+    const LayerDesc& l1 = a.layers[2 * b];
+    const LayerDesc& l2 = a.layers[2 * b + 1];
+    const int C = l1.N;
+    // second half: GroupNorm+SiLU backward, wgrad, dgrad
+    GnBwdArgs ga{};
+    ga.g = W.g_out[b]; ga.z = W.f.z2[b]; ga.stats = W.f.st2[b]; ga.gamma = h->params[l2.gamma]; ga.beta = h->params[l2.beta];
+    ga.gz = W.g_z2[b]; ga.dgamma = grads[l2.gamma]; ga.dbeta = grads[l2.beta]; ga.dbias = grads[l2.b];
+    ga.rows = n; ga.C = C; ga.drop_mode = 0;
+    OSD_HIP(launch_gn_silu_bwd(s, l2.gw, ga));
+    OSD_HIP(wgrad(s, W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C));
+    OSD_HIP(dgrad(s, h->params[l2.w], C, C, W.g_z2[b], C, C, n, W.g_mid[b], C, false));
+    // first half (dropout sits behind it)
+    GnBwdArgs gb{};
+    gb.g = W.g_mid[b]; gb.z = W.f.z1[b]; gb.stats = W.f.st1[b]; gb.gamma = h->params[l1.gamma]; gb.beta = h->params[l1.beta];
+    gb.gz = W.g_z1[b]; gb.dgamma = grads[l1.gamma]; gb.dbeta = grads[l1.beta]; gb.dbias = grads[l1.b];
+    gb.rows = n; gb.C = C;
+    gb.drop_mode = drop ? (masks ? 1 : 2) : 0;
+    gb.mask = (drop && masks) ? masks[b] : nullptr; gb.keep_scale = keep_scale; gb.p_drop = h->cfg.dropout_p;
+    gb.seed = seed; gb.row_offset = roff; gb.step = 0; gb.tag = TAG_DROPOUT + (uint32_t)b;
+    OSD_HIP(launch_gn_silu_bwd(s, l1.gw, gb));
+    const int Kt = l1.K1 + l1.K2;
+    const float* xin = (b == 0) ? W.f.h0 : W.f.out[b - 1];
+    OSD_HIP(wgrad(s, xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt));
+    int skip_block = -1;
+    if (l1.K2 > 0) {
+      skip_block = a.n_enc - 1 - (b - a.n_enc - 1);
+      OSD_HIP(wgrad(s, W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt));
+    }
+    OSD_TRY(record());
+    // dgrad into the producer of the main input; encoder outputs already hold their skip gradient
+    float* gdst = (b == 0) ? W.g_h0 : W.g_out[b - 1];
+    const bool acc = (b >= 1) && (b - 1 < a.n_enc);
+    OSD_HIP(dgrad(s, h->params[l1.w], Kt, l1.K1, W.g_z1[b], C, C, n, gdst, l1.K1, acc));
+    if (l1.K2 > 0) OSD_HIP(dgrad(s, h->params[l1.w] + l1.K1, Kt, l1.K2, W.g_z1[b], C, C, n, W.g_out[skip_block], l1.K2, false));
+  }
+  // input_proj, time_proj, cond_proj, ConditionalEmbedding  (h0 = x W^T + b + t_emb[t] + c_proj)
+  OSD_HIP(wgrad(s, W.x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D));
+  OSD_HIP(launch_colsum(s, W.g_h0, a.H0, n, a.H0, grads[pm.in_b]));
+  OSD_HIP(hipMemcpyAsync(grads[pm.cp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s));
+  OSD_HIP(hipMemcpyAsync(grads[pm.tp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s));
+  OSD_HIP(launch_scatter_rows(s, W.g_h0, t_idx, n, a.H0, W.g_temb));
+  OSD_HIP(wgrad(s, h->d_time_emb, a.time_dim, a.time_dim, W.g_temb, a.H0, a.H0, a.T, grads[pm.tp_w], a.time_dim));
+  OSD_HIP(wgrad(s, W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64));
+  OSD_HIP(dgrad(s, h->params[pm.cp_w], 64, 64, W.g_h0, a.H0, a.H0, n, W.g_ce2, 64, false));
+  OSD_HIP(wgrad(s, W.f.ce1, 64, 64, W.g_ce2, 64, 64, n, grads[pm.ce2_w], 64));
+  OSD_HIP(launch_colsum(s, W.g_ce2, 64, n, 64, grads[pm.ce2_b]));
+  OSD_HIP(dgrad(s, h->params[pm.ce2_w], 64, 64, W.g_ce2, 64, 64, n, W.g_ce1, 64, false));
+  OSD_HIP(launch_silu_bwd(s, W.u0, W.g_ce1, W.g_u, n * 64));
+  OSD_HIP(wgrad(s, cond, a.cond_dim, a.cond_dim, W.g_u, 64, 64, n, grads[pm.ce0_w], a.cond_dim));
+  OSD_HIP(launch_colsum(s, W.g_u, 64, n, 64, grads[pm.ce0_b]));
+  OSD_TRY(record());
+  if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
+  return OSD_OK;
+}
+
+int osd_clip_adamw_step(osd_handle* h, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, float max_norm, int64_t step, float* grad_norm_out) {
+  if (!h || !param || !grad || !exp_avg || !exp_avg_sq) { set_error("null argument"); return OSD_EINVAL; }
+  if (numel <= 0 || step < 1) { set_error("numel and step must be positive"); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  if (!h->normsq_dev) OSD_HIP(hipMalloc((void**)&h->normsq_dev, 64));
+  AdamArgs a{};
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  a.decay = (float)(1.0 - (double)lr * (double)weight_decay);
+  a.one_minus_b1 = (float)(1.0 - (double)beta1);
+  a.b2 = beta2;
+  a.one_minus_b2 = (float)(1.0 - (double)beta2);
+  a.bc2_sqrt = (float)sqrt(bc2);
+  a.eps = eps;
+  a.neg_step_size = (float)(-((double)lr / bc1));
+  a.max_norm = max_norm;
+  OSD_HIP(launch_clip_adamw(h->stream, param, grad, exp_avg, exp_avg_sq, numel, a, h->normsq_dev, grad_norm_out));
+  return OSD_OK;
+}
+
+}  // extern "C"
