@@ -141,7 +141,7 @@ int osd_sample_chain(osd_handle *h, const float *cond, int64_t n, const float *x
 int osd_train_loss_fwd_bwd(osd_handle *h, const float *x0, const float *cond, int64_t n,
                            const int32_t *t_index, const float *noise, const float *const *masks,
                            uint64_t seed, int64_t row_offset, int flags, float *loss_out,
-                           float *const *grads, float loss_scale, void *const *events, int n_events);
+                           float *const *grads, double loss_scale, void *const *events, int n_events);
 
 /* Gradient buckets in the order backward finalises them: bucket b covers parameters
  * [first, last] (indices in named_parameters() order).  Returns the bucket count. */
@@ -150,16 +150,24 @@ int osd_grad_buckets(const osd_config *cfg, int32_t *first, int32_t *last, int m
 /* MixupAugmentation.__call__ (utils/train.py:108-120): out = lam*v + (1-lam)*v[perm]
  * for data[n][D], conditions[n][cond_dim], survival[n]; perm dev int64[n]. */
 int osd_mixup(osd_handle *h, const float *data, const float *cond, const float *surv,
-              const int64_t *perm, float lam, int64_t n, float *data_out, float *cond_out,
+              const int64_t *perm, double lam, int64_t n, float *data_out, float *cond_out,
               float *surv_out);
 
 /* clip_grad_norm_(max_norm) + AdamW.step (utils/train.py:242-244, 169-173) over flat
  * contiguous buffers of `numel` floats.  step is the 1-based count after increment.
  * grad_norm_out (dev float[1], may be NULL) receives the pre-clip global L2 norm.
- * max_norm <= 0 disables clipping. */
+ * max_norm <= 0 disables clipping.  Hyper-parameters are python floats (doubles): derived
+ * scalars such as 1 - beta2 are formed in double and rounded to fp32 once, as torch does. */
 int osd_clip_adamw_step(osd_handle *h, float *param, float *grad, float *exp_avg, float *exp_avg_sq,
-                        int64_t numel, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, float max_norm, int64_t step, float *grad_norm_out);
+                        int64_t numel, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, double max_norm, int64_t step, float *grad_norm_out);
+
+/* Measurement aid for bench.py: per-launch HIP-event timing of one reverse step on n rows
+ * (eager launches on the handle's stream, averaged over reps after one warm-up pass).
+ * Entry 0 = input_proj, 1..2*n_blocks = the Linear+GroupNorm+SiLU halves in execution order,
+ * last = output_proj+posterior.  flop_out = algorithmic GEMM FLOPs of each launch. */
+int osd_profile_step(osd_handle *h, const float *cond, int64_t n, int reps, float *ms_out,
+                     double *flop_out, int max_entries, int *n_entries);
 
 /* ---- building blocks, exported for the parity tests ------------------------ */
 /* y[n][N] = act(x[n][K] @ w[N][K]^T + b), act = identity (silu=0) or SiLU. */

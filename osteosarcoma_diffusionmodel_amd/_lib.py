@@ -42,11 +42,12 @@ _SIGNATURES = {
     "osd_p_sample_step": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int64, C.c_uint64, C.c_int64, _P, C.c_int]),
     "osd_sample_chain": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_uint64, C.c_int64, _P, _P, C.c_int]),
     "osd_train_loss_fwd_bwd": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, C.POINTER(_P), C.c_uint64, C.c_int64, C.c_int,
-                                         _P, C.POINTER(_P), C.c_float, C.POINTER(_P), C.c_int]),
+                                         _P, C.POINTER(_P), C.c_double, C.POINTER(_P), C.c_int]),
     "osd_grad_buckets": (C.c_int, [C.POINTER(OsdConfig), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]),
-    "osd_mixup": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_int64, _P, _P, _P]),
-    "osd_clip_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
-                                      C.c_float, C.c_float, C.c_int64, _P]),
+    "osd_mixup": (C.c_int, [_P, _P, _P, _P, _P, C.c_double, C.c_int64, _P, _P, _P]),
+    "osd_clip_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                      C.c_double, C.c_double, C.c_int64, _P]),
+    "osd_profile_step": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
     "osd_op_linear": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     "osd_op_linear_gn_silu": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int, _P]),
     "osd_op_gemm": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int]),

@@ -138,6 +138,14 @@ int run_cond(osd_handle* h, hipStream_t s, const float* cond, int64_t n, const F
   return OSD_OK;
 }
 
+static int prof_mark(osd_handle* h, hipStream_t s) {
+  if (h->prof_events) {
+    if (h->prof_i >= (int)h->prof_events->size()) { set_error("profile event overflow"); return OSD_EINVAL; }
+    OSD_HIP(hipEventRecord((*h->prof_events)[h->prof_i++], s));
+  }
+  return OSD_OK;
+}
+
 // input_proj + blocks (models/diffusion.py:229-251); result in ws.out[n_blocks-1].
 int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) {
   const Arch& a = h->arch;
@@ -149,6 +157,7 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
     g.F = a.H0; g.P = n; g.K = a.D;
     EpiInput::Args ea{h->params[pm.in_b], h->d_temb, a.H0, in.t_index, in.t_dev, in.t_imm, ws.cproj, a.H0, ws.h0, a.H0};
     OSD_HIP(launch_input(s, g, ea));
+    OSD_TRY(prof_mark(h, s));
   }
   const float* cur = ws.h0;
   int cur_w = a.H0;
@@ -178,6 +187,7 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
     } else {
       OSD_HIP(launch_gn_silu(s, g, l1.gw, ga));
     }
+    OSD_TRY(prof_mark(h, s));
     GemmArgs g2{};
     g2.A = h->params[l2.w]; g2.lda = l2.K1; g2.B0 = ws.mid[b]; g2.ldb0 = l1.N; g2.K0 = l2.K1;
     g2.F = l2.N; g2.P = n; g2.K = l2.K1;
@@ -186,6 +196,7 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
     gb.out = ws.out[b]; gb.ldo = l2.N;
     gb.z_out = in.save ? ws.z2[b] : nullptr; gb.ldz = l2.N; gb.stats = in.save ? ws.st2[b] : nullptr;
     OSD_HIP(launch_gn_silu(s, g2, l2.gw, gb));
+    OSD_TRY(prof_mark(h, s));
     cur = ws.out[b];
     cur_w = l2.N;
   }
@@ -514,7 +525,7 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
   return OSD_OK;
 }
 
-int osd_mixup(osd_handle* h, const float* data, const float* cond, const float* surv, const int64_t* perm, float lam, int64_t n,
+int osd_mixup(osd_handle* h, const float* data, const float* cond, const float* surv, const int64_t* perm, double lam, int64_t n,
               float* data_out, float* cond_out, float* surv_out) {
   if (!h) { set_error("null handle"); return OSD_EINVAL; }
   OSD_TRY(check_rows(n));
@@ -523,6 +534,69 @@ int osd_mixup(osd_handle* h, const float* data, const float* cond, const float* 
   if (data && data_out) OSD_HIP(launch_mixup(h->stream, data, perm, lam, n, h->arch.D, data_out));
   if (cond && cond_out) OSD_HIP(launch_mixup(h->stream, cond, perm, lam, n, h->arch.cond_dim, cond_out));
   if (surv && surv_out) OSD_HIP(launch_mixup(h->stream, surv, perm, lam, n, 1, surv_out));
+  return OSD_OK;
+}
+
+// Per-launch timing of one reverse step with HIP events on the handle's stream (bench.py's
+// roofline leg): launch i of the step (0 = input_proj, 1.. = the block halves in execution
+// order, last = output_proj + posterior) averaged over `reps` eager steps at t = T/2.
+int osd_profile_step(osd_handle* h, const float* cond, int64_t n, int reps, float* ms_out, double* flop_out, int max_entries,
+                     int* n_entries) {
+  OSD_TRY(check_ready(h));
+  OSD_TRY(check_rows(n));
+  if (!cond || !ms_out || !flop_out || !n_entries || n <= 0 || reps <= 0) { set_error("bad argument"); return OSD_EINVAL; }
+  const Arch& a = h->arch;
+  const int n_launch = 2 + 2 * a.n_blocks;
+  if (max_entries < n_launch) { set_error("need room for %d entries", n_launch); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  hipStream_t s = h->stream;
+  FwdWs ws;
+  const int64_t fwd = carve_fwd(a, nullptr, n, false, &ws);
+  const int64_t need = fwd + align_up(n * a.D, 64);
+  OSD_TRY(ensure_arena(&h->main, need));
+  carve_fwd(a, h->main.arena, n, false, &ws);
+  float* x = h->main.arena + fwd;
+  OSD_TRY(run_cond(h, s, cond, n, ws));
+  OSD_HIP(launch_fill_randn(s, x, a.D, n, a.D, 1, 0, (uint32_t)a.T, TAG_POSTERIOR));
+  std::vector<hipEvent_t> evs((size_t)n_launch + 1);
+  for (auto& e : evs) OSD_HIP(hipEventCreate(&e));
+  std::vector<double> acc((size_t)n_launch, 0.0);
+  int rc = OSD_OK;
+  for (int r = 0; r < reps + 1 && rc == OSD_OK; ++r) {       // first pass warms up, untimed
+    h->prof_events = &evs;
+    h->prof_i = 0;
+    hipError_t e = hipEventRecord(evs[h->prof_i++], s);
+    TrunkIn in{};
+    in.x = x; in.ldx = a.D; in.n = n; in.t_imm = a.T / 2;
+    if (e == hipSuccess) rc = run_trunk(h, s, ws, in);
+    if (rc == OSD_OK && e == hipSuccess) {
+      GemmArgs g = output_proj_args(h, ws, n);
+      EpiPosterior::Args ea{};
+      ea.bias = h->params[a.pm.out_b]; ea.xin = x; ea.ldx = a.D; ea.xout = x; ea.ldo = a.D; ea.coef = h->d_coef;
+      ea.t_imm = a.T / 2; ea.ldzz = a.D; ea.seed = 1; ea.t_first = a.T / 2;
+      e = launch_posterior(s, g, ea);
+      if (e == hipSuccess) e = hipEventRecord(evs[h->prof_i++], s);
+    }
+    h->prof_events = nullptr;
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { set_error("profile step failed: %s", hipGetErrorString(e)); rc = OSD_EHIP; break; }
+    if (r == 0) continue;
+    for (int i = 0; i < n_launch; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, evs[i], evs[i + 1]) == hipSuccess) acc[i] += ms;
+    }
+  }
+  h->prof_events = nullptr;
+  for (auto& e : evs) { hipError_t x2 = hipEventDestroy(e); (void)x2; }
+  if (rc != OSD_OK) return rc;
+  for (int i = 0; i < n_launch; ++i) ms_out[i] = (float)(acc[i] / reps);
+  flop_out[0] = 2.0 * (double)n * a.D * a.H0;
+  for (int i = 0; i < 2 * a.n_blocks; ++i) {
+    const LayerDesc& l = a.layers[i];
+    flop_out[1 + i] = 2.0 * (double)n * (l.K1 + l.K2) * l.N;
+  }
+  flop_out[n_launch - 1] = 2.0 * (double)n * a.block_out[a.n_blocks - 1] * a.D;
+  *n_entries = n_launch;
   return OSD_OK;
 }
 

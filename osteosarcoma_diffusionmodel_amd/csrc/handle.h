@@ -99,4 +99,7 @@ struct osd_handle {
   int64_t train_arena_floats = 0;
   float* loss_dev = nullptr;
   double* normsq_dev = nullptr;
+  // osd_profile_step: when non-null, run_trunk records prof_events[prof_i++] after every launch
+  std::vector<hipEvent_t>* prof_events = nullptr;
+  int prof_i = 0;
 };

@@ -110,11 +110,11 @@ __global__ void k_mixup(const float* v, const int64_t* perm, float lam, float om
     st4g(out + r * cols, c, cols, o);
   }
 }
-hipError_t launch_mixup(hipStream_t s, const float* v, const int64_t* perm, float lam, int64_t rows, int cols, float* out) {
+hipError_t launch_mixup(hipStream_t s, const float* v, const int64_t* perm, double lam, int64_t rows, int cols, float* out) {
   if (rows <= 0) return hipSuccess;
   // python: lam and (1 - lam) are float64 scalars; torch multiplies an fp32 tensor by each as fp32
-  const float oml = (float)(1.0 - (double)lam);
-  hipLaunchKernelGGL(k_mixup, ew_grid(rows * ((cols + 3) / 4)), 256, 0, s, v, perm, lam, oml, rows, cols, out);
+  const float oml = (float)(1.0 - lam);
+  hipLaunchKernelGGL(k_mixup, ew_grid(rows * ((cols + 3) / 4)), 256, 0, s, v, perm, (float)lam, oml, rows, cols, out);
   return hipGetLastError();
 }
 

@@ -78,7 +78,7 @@ int osd_grad_buckets(const osd_config* cfg, int32_t* first, int32_t* last, int m
 
 int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, int64_t n, const int32_t* t_index, const float* noise,
                            const float* const* masks, uint64_t seed, int64_t row_offset, int flags, float* loss_out,
-                           float* const* grads, float loss_scale, void* const* events, int n_events) {
+                           float* const* grads, double loss_scale, void* const* events, int n_events) {
   OSD_TRY(check_ready(h));
   OSD_TRY(check_rows(n));
   if (!x0 || !cond || !loss_out) { set_error("null tensor"); return OSD_EINVAL; }
@@ -234,23 +234,23 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   return OSD_OK;
 }
 
-int osd_clip_adamw_step(osd_handle* h, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, float lr,
-                        float beta1, float beta2, float eps, float weight_decay, float max_norm, int64_t step, float* grad_norm_out) {
+int osd_clip_adamw_step(osd_handle* h, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, double lr,
+                        double beta1, double beta2, double eps, double weight_decay, double max_norm, int64_t step, float* grad_norm_out) {
   if (!h || !param || !grad || !exp_avg || !exp_avg_sq) { set_error("null argument"); return OSD_EINVAL; }
   if (numel <= 0 || step < 1) { set_error("numel and step must be positive"); return OSD_EINVAL; }
   OSD_HIP(hipSetDevice(h->cfg.device));
   if (!h->normsq_dev) OSD_HIP(hipMalloc((void**)&h->normsq_dev, 64));
   AdamArgs a{};
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  a.decay = (float)(1.0 - (double)lr * (double)weight_decay);
-  a.one_minus_b1 = (float)(1.0 - (double)beta1);
-  a.b2 = beta2;
-  a.one_minus_b2 = (float)(1.0 - (double)beta2);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  a.decay = (float)(1.0 - lr * weight_decay);
+  a.one_minus_b1 = (float)(1.0 - beta1);
+  a.b2 = (float)beta2;
+  a.one_minus_b2 = (float)(1.0 - beta2);
   a.bc2_sqrt = (float)sqrt(bc2);
-  a.eps = eps;
-  a.neg_step_size = (float)(-((double)lr / bc1));
-  a.max_norm = max_norm;
+  a.eps = (float)eps;
+  a.neg_step_size = (float)(-(lr / bc1));
+  a.max_norm = (float)max_norm;
   OSD_HIP(launch_clip_adamw(h->stream, param, grad, exp_avg, exp_avg_sq, numel, a, h->normsq_dev, grad_norm_out));
   return OSD_OK;
 }

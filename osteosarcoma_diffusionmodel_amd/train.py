@@ -103,7 +103,7 @@ class _DiffusionLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x0, cond, t, noise, masks, seed, *params):
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need_grad = any(ctx.needs_input_grad[7:])      # grad mode is off inside Function.forward
         if not need_grad:
             ctx.grads = None
             return _loss_fwd_bwd(model, x0, cond, None, t=t, noise=noise, dropout_masks=masks, seed=seed).reshape(())

@@ -60,7 +60,8 @@ def test_gemm_accumulate(rh):
     Af = torch.randn(F_, K, generator=g, dtype=torch.float64)
     Bf = torch.randn(P, K, generator=g, dtype=torch.float64)
     C0 = torch.randn(P, F_, generator=g, dtype=torch.float64)
-    out = _gemm(rh, Af.T.contiguous().float().cuda(), 0, Bf.float().cuda(), 1, F_, P, K, C0.float().cuda())
+    Ad, Bd, Cd = Af.T.contiguous().float().cuda(), Bf.float().cuda(), C0.float().cuda()
+    out = _gemm(rh, Ad, 0, Bd, 1, F_, P, K, Cd)
     assert_close(out.cpu(), C0 + Bf @ Af.T, RTOL, what="dgrad accumulate")
 
 
@@ -74,7 +75,8 @@ def test_linear(rh, n, K, N, silu):
     if silu:
         ref = F.silu(ref)
     y = torch.empty(n, N, device="cuda")
-    L.check(L.lib().osd_op_linear(rh.h, L.ptr(x.cuda()), L.ptr(w.cuda()), L.ptr(b.cuda()), n, K, N, silu, L.ptr(y)))
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()          # keep the device tensors alive across the async call
+    L.check(L.lib().osd_op_linear(rh.h, L.ptr(xd), L.ptr(wd), L.ptr(bd), n, K, N, silu, L.ptr(y)))
     torch.cuda.synchronize()
     assert_close(y.cpu(), ref, RTOL, what=f"linear n={n} K={K} N={N}")
 
@@ -96,8 +98,9 @@ def test_linear_gn_silu(rh, N, n, K1, K2):
     x1 = x[:, :K1].contiguous().cuda()
     x2 = x[:, K1:].contiguous().cuda() if K2 else None
     y = torch.empty(n, N, device="cuda")
-    L.check(L.lib().osd_op_linear_gn_silu(rh.h, L.ptr(x1), K1, L.ptr(x2), K2, L.ptr(w.cuda()), L.ptr(b.cuda()),
-                                          L.ptr(gamma.cuda()), L.ptr(beta.cuda()), n, N, L.ptr(y)))
+    wd, bd, gd, bed = w.cuda(), b.cuda(), gamma.cuda(), beta.cuda()
+    L.check(L.lib().osd_op_linear_gn_silu(rh.h, L.ptr(x1), K1, L.ptr(x2), K2, L.ptr(wd), L.ptr(bd),
+                                          L.ptr(gd), L.ptr(bed), n, N, L.ptr(y)))
     torch.cuda.synchronize()
     assert_close(y.cpu(), ref, RTOL, atol=1e-6, what=f"linear_gn_silu N={N} n={n} K=({K1},{K2})")
 

@@ -119,7 +119,8 @@ def test_mixup_kernel(golden_dir):
     eng = m._engine()
     from osteosarcoma_diffusionmodel_amd import _lib as L
     od, oc, os_ = torch.empty_like(data), torch.empty_like(cond), torch.empty_like(surv)
-    L.check(L.lib().osd_mixup(eng.handle, L.ptr(data), L.ptr(cond), L.ptr(surv), L.ptr(perm.cuda()), lam, 16,
+    perm_d = perm.cuda()
+    L.check(L.lib().osd_mixup(eng.handle, L.ptr(data), L.ptr(cond), L.ptr(surv), L.ptr(perm_d), lam, 16,
                               L.ptr(od), L.ptr(oc), L.ptr(os_)))
     rd, rc, rs = O.mixup(data.cpu(), cond.cpu(), surv.cpu(), lam, perm)
     assert np.array_equal(od.cpu().numpy(), rd.numpy())
@@ -177,7 +178,8 @@ def test_trainer_epoch_vs_reference(golden_dir, tmp_path):
         sl = slice(16 * it, 16 * it + 16)
         data, cond, surv = dev(g["data"][sl]), dev(g["cond"][sl]), dev(g["surv"][sl])
         od, oc, os_ = torch.empty_like(data), torch.empty_like(cond), torch.empty_like(surv)
-        L.check(L.lib().osd_mixup(eng.handle, L.ptr(data), L.ptr(cond), L.ptr(surv), L.ptr(dev(g["perm"][it])), float(g["lam"][it]),
+        perm_d = dev(g["perm"][it])
+        L.check(L.lib().osd_mixup(eng.handle, L.ptr(data), L.ptr(cond), L.ptr(surv), L.ptr(perm_d), float(g["lam"][it]),
                                   16, L.ptr(od), L.ptr(oc), L.ptr(os_)))
         losses.append(tr.train_step(od, oc, t=dev(g["t"][it]), noise=dev(g["noise"][it])).item())
     assert_close(np.mean(losses), g["avg_loss"], 1e-5, what="epoch loss")
