@@ -129,3 +129,16 @@ def test_randn_stream(rh):
     y = d.double().cpu().numpy().ravel()
     assert abs(np.corrcoef(x, y)[0, 1]) < 5 / np.sqrt(n)
     assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 5 / np.sqrt(n)
+
+
+def test_randn_matches_host_philox(rh):
+    """Device normals == Box-Muller over a host restatement of Philox4x32-10 (Random123 KAT-checked)."""
+    from helpers import TAG_POSTERIOR, TAG_QNOISE, philox4x32_10, philox_normals
+    kat = philox4x32_10(np.uint32(0x243f6a88), np.uint32(0x85a308d3), np.uint32(0x13198a2e), np.uint32(0x03707344), 0xa4093822, 0x299f31d0)
+    assert [int(v) for v in kat] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    rows, cols, seed = 257, 2000, (9 << 33) + 12345
+    for step, kind, tag, off in ((1000, 0, TAG_POSTERIOR, 0), (17, 0, TAG_POSTERIOR, 4000), (0, 1, TAG_QNOISE, 123)):
+        a = torch.empty(rows, cols, device="cuda")
+        L.check(L.lib().osd_op_randn(rh.h, L.ptr(a), rows, cols, seed, off, step, kind))
+        ref = philox_normals(seed, rows, cols, step, tag, off)
+        assert np.abs(a.cpu().numpy() - ref).max() < 2e-5

@@ -84,31 +84,54 @@ def test_full_shape_grads_vs_oracle():
         assert_close(p.grad.cpu(), ref_grads[k], GRAD_RTOL, atol=1e-9, what=f"grad {k}")
 
 
-def test_philox_dropout_gradient_is_consistent(golden_dir):
-    """Train mode with in-kernel Philox masks: backward regenerates the forward's masks, so a
-    directional finite difference of the loss matches <grad, v>."""
+def test_philox_dropout_grads_vs_oracle(golden_dir):
+    """Train mode with in-kernel Philox masks at a multi-tile batch: the oracle, fed the host
+    restatement of those masks, reproduces loss and gradients (backward regenerates the masks)."""
+    from helpers import philox_keep_mask
     m = small_model(golden_dir).train()
-    g = load_golden(golden_dir, "g3g4_small_model")
-    x = torch.randn(512, 40, generator=torch.Generator().manual_seed(0)).cuda()
-    cond = torch.randn(512, 3, generator=torch.Generator().manual_seed(1)).cuda()
-    t = torch.randint(0, 1000, (512,), generator=torch.Generator().manual_seed(2)).cuda()
-    noise = torch.randn(512, 40, generator=torch.Generator().manual_seed(3)).cuda()
-    kw = dict(t=t, noise=noise, seed=77)
-    loss = m(x, cond, **kw)
+    sd = {k: v for k, v in golden_small_sd(golden_dir).items() if k.startswith(("condition_embed", "unet"))}
+    n, seed = 512, 77
+    x = torch.randn(n, 40, generator=torch.Generator().manual_seed(0))
+    cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(1))
+    t = torch.randint(0, 1000, (n,), generator=torch.Generator().manual_seed(2))
+    noise = torch.randn(n, 40, generator=torch.Generator().manual_seed(3))
+    loss = m(x.cuda(), cond.cuda(), t=t.cuda(), noise=noise.cuda(), seed=seed)
     loss.backward()
-    loss_eval = small_model(golden_dir)(x, cond, t=t, noise=noise)
-    assert abs(loss.item() - loss_eval.item()) > 1e-4          # dropout really is active
-    assert loss.item() == m(x, cond, **kw).item()               # same seed, same masks
-    p = m.unet.bottleneck[4].weight
-    v = torch.randn(p.shape, generator=torch.Generator().manual_seed(4)).cuda()
-    analytic = float((p.grad * v).sum())
-    eps = 2e-2
-    with torch.no_grad():
-        p.add_(eps * v); lp = m(x, cond, **kw).item()
-        p.add_(-2 * eps * v); lm = m(x, cond, **kw).item()
-        p.add_(eps * v)
-    fd = (lp - lm) / (2 * eps)
-    assert abs(fd - analytic) <= 0.05 * abs(analytic) + 1e-5, (fd, analytic)
+    again = m(x.cuda(), cond.cuda(), t=t.cuda(), noise=noise.cuda(), seed=seed).item()
+    assert abs(loss.item() - again) < 1e-6 * abs(again)      # same seed, same masks (the loss sum uses float atomics)
+    loss_eval = small_model(golden_dir)(x.cuda(), cond.cuda(), t=t.cuda(), noise=noise.cuda())
+    assert abs(loss.item() - loss_eval.item()) > 1e-4                                                # dropout is active
+    masks = [torch.from_numpy(philox_keep_mask(seed, n, w, b, 0.2)) for b, w in enumerate([64, 32, 32, 64, 32])]
+    bufs = {k: v.cpu() for k, v in m.state_dict().items() if "alpha" in k or k == "betas"}
+    ref_loss, ref_grads = O.training_loss_and_grads(sd, bufs, x, cond, t, noise, 3, 128, masks, 0.2)
+    assert_close(loss.item(), ref_loss, 1e-5, what="loss")
+    for k, p in m.named_parameters():
+        assert_close(p.grad.cpu(), ref_grads[k], GRAD_RTOL, atol=1e-8, what=f"grad {k}")
+
+
+def test_philox_dropout_equals_injected_masks(golden_dir):
+    """The in-kernel Philox keep-masks are exactly the masks a host restatement of Philox4x32-10
+    produces; with those injected, loss and every gradient agree with the Philox run."""
+    from helpers import philox_keep_mask
+    m = small_model(golden_dir).train()
+    n = 300
+    x = torch.randn(n, 40, generator=torch.Generator().manual_seed(0)).cuda()
+    cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    t = torch.randint(0, 1000, (n,), generator=torch.Generator().manual_seed(2)).cuda()
+    noise = torch.randn(n, 40, generator=torch.Generator().manual_seed(3)).cuda()
+    seed = (5 << 40) + 77
+    loss_a = m(x, cond, t=t, noise=noise, seed=seed)
+    loss_a.backward()
+    ga = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    widths = [64, 32, 32, 64, 32]
+    masks = [torch.from_numpy(philox_keep_mask(seed, n, w, b, 0.2)).cuda() for b, w in enumerate(widths)]
+    assert 0.7 < float(masks[0].mean()) < 0.9
+    loss_b = m(x, cond, t=t, noise=noise, dropout_masks=masks)
+    loss_b.backward()
+    assert_close(loss_a.item(), loss_b.item(), 1e-6, what="loss philox vs injected")
+    for k, p in m.named_parameters():
+        assert_close(ga[k].cpu(), p.grad.cpu(), 1e-5, atol=1e-9, what=f"grad {k}")
 
 
 def test_mixup_kernel(golden_dir):
@@ -156,7 +179,7 @@ def test_fused_clip_adamw_vs_torch():
         assert_close(p.cpu(), ref.detach(), 1e-6, what=f"param step {step}")
     st = opt.state[ref]
     assert_close(mm.cpu(), st["exp_avg"], 1e-6)
-    assert_close(vv.cpu(), st["exp_avg_sq"], 1e-6)
+    assert_close(vv.cpu(), st["exp_avg_sq"], 5e-6)
 
 
 def test_trainer_epoch_vs_reference(golden_dir, tmp_path):
