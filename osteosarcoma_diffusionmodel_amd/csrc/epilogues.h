@@ -1,4 +1,9 @@
 // epilogues.h -- fused epilogues for gemm_kernel (see gemm.h for the fragment layout).
+//
+// Every epilogue loads its side inputs from CLAMPED indices (always in range) and guards only
+// the stores, so in FAST mode no load sits behind a branch and the compiler issues them all
+// before a single wait.  fast_ok() tells the host whether FAST's alignment/divisibility
+// preconditions hold for the epilogue's own pointers.
 #pragma once
 #include "gemm.h"
 #include "rng.h"
@@ -9,24 +14,26 @@ constexpr float GN_EPS = 1e-5f;
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // ---- bias (+ optional SiLU, + optional accumulate into out) -----------------------
 template <bool SILU, bool ACCUM>
 struct EpiBias {
   struct Args { const float* bias; float* out; int ldo; };
-  template <int NFB, int NPB>
+  static bool fast_ok(const Args& a, int F) { return F % 4 == 0 && al16(a.bias) && al16(a.out) && a.ldo % 4 == 0; }
+  template <int NFB, int NPB, bool FAST>
   static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, int fw, int pw, int lane, int F, int P) {
     const int l31 = lane & 31, h = lane >> 5;
     OSD_FOR_QUADS(fb, pb, q) {
       const int f = fw + 32 * fb + 8 * q + 4 * h;
       const int p = pw + 32 * pb + l31;
-      if (p < P && f < F) {
-        float4 v = make_float4(acc[fb][pb][4 * q], acc[fb][pb][4 * q + 1], acc[fb][pb][4 * q + 2], acc[fb][pb][4 * q + 3]);
-        if (a.bias) { const float4 bv = ld4g(a.bias, f, F); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
-        float* row = a.out + (size_t)p * a.ldo;
-        if (ACCUM) { const float4 o = ld4g(row, f, F); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        if (SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-        st4g(row, f, F, v);
-      }
+      const int pc = p < P ? p : P - 1;
+      float4 v = make_float4(acc[fb][pb][4 * q], acc[fb][pb][4 * q + 1], acc[fb][pb][4 * q + 2], acc[fb][pb][4 * q + 3]);
+      if (a.bias) { const float4 bv = ldq<FAST>(a.bias, f, F); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+      float* row = a.out + (size_t)pc * a.ldo;
+      if (ACCUM) { const float4 o = ldq<FAST>(row, f, F); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      if (SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+      if (p < P) stq<FAST>(row, f, F, v);
     }
   }
 };
@@ -41,31 +48,33 @@ struct EpiInput {
     const float* cproj; int ldc;  // [P][F]
     float* out; int ldo;
   };
-  template <int NFB, int NPB>
+  static bool fast_ok(const Args& a, int F) {
+    return F % 4 == 0 && al16(a.bias) && al16(a.temb) && al16(a.cproj) && al16(a.out) && a.ldt % 4 == 0 && a.ldc % 4 == 0 && a.ldo % 4 == 0;
+  }
+  template <int NFB, int NPB, bool FAST>
   static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, int fw, int pw, int lane, int F, int P) {
     const int l31 = lane & 31, h = lane >> 5;
     const int t_shared = a.t_dev ? *a.t_dev : a.t_imm;
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) {
       const int p = pw + 32 * pb + l31;
-      if (p >= P) continue;
-      const int t = a.t_index ? a.t_index[p] : t_shared;
+      const int pc = p < P ? p : P - 1;
+      const int t = a.t_index ? a.t_index[pc] : t_shared;
       const float* trow = a.temb + (size_t)t * a.ldt;
-      const float* crow = a.cproj + (size_t)p * a.ldc;
-      float* orow = a.out + (size_t)p * a.ldo;
+      const float* crow = a.cproj + (size_t)pc * a.ldc;
+      float* orow = a.out + (size_t)pc * a.ldo;
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int f = fw + 32 * fb + 8 * q + 4 * h;
-          if (f >= F) continue;
-          const float4 bv = ld4g(a.bias, f, F), tv = ld4g(trow, f, F), cv = ld4g(crow, f, F);
+          const float4 bv = ldq<FAST>(a.bias, f, F), tv = ldq<FAST>(trow, f, F), cv = ldq<FAST>(crow, f, F);
           float4 v;
           v.x = ((acc[fb][pb][4 * q] + bv.x) + tv.x) + cv.x;
           v.y = ((acc[fb][pb][4 * q + 1] + bv.y) + tv.y) + cv.y;
           v.z = ((acc[fb][pb][4 * q + 2] + bv.z) + tv.z) + cv.z;
           v.w = ((acc[fb][pb][4 * q + 3] + bv.w) + tv.w) + cv.w;
-          st4g(orow, f, F, v);
+          if (p < P) stq<FAST>(orow, f, F, v);
         }
     }
   }
@@ -91,7 +100,11 @@ struct EpiGnSilu {
     uint64_t seed; uint32_t row_offset; uint32_t step; uint32_t tag;   // drop_mode 2
     const int* step_dev;              // drop_mode 2: step = *step_dev when non-null
   };
-  template <int NFB, int NPB>
+  static bool fast_ok(const Args& a, int F) {
+    return F % 4 == 0 && al16(a.bias) && al16(a.gamma) && al16(a.beta) && al16(a.out) && a.ldo % 4 == 0 &&
+           (!a.z_out || (al16(a.z_out) && a.ldz % 4 == 0)) && (a.drop_mode != 1 || (al16(a.mask) && a.ldm % 4 == 0));
+  }
+  template <int NFB, int NPB, bool FAST>
   static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, int fw, int pw, int lane, int F, int P) {
     static_assert(NFB * 32 >= GW, "wave must own whole groups");
     constexpr int RPG = (GW >= 8) ? GW / 2 : 4;   // registers of one group in this lane
@@ -103,7 +116,7 @@ struct EpiGnSilu {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int f = fw + 32 * fb + 8 * q + 4 * h;
-        const float4 bv = ld4g(a.bias, f, F);
+        const float4 bv = ldq<FAST>(a.bias, f, F);
 #pragma unroll
         for (int pb = 0; pb < NPB; ++pb) {
           acc[fb][pb][4 * q] += bv.x; acc[fb][pb][4 * q + 1] += bv.y;
@@ -114,6 +127,7 @@ struct EpiGnSilu {
     for (int pb = 0; pb < NPB; ++pb) {
       const int p = pw + 32 * pb + l31;
       const bool prow = p < P;
+      const int pc = prow ? p : P - 1;
       float mean[NG], rstd[NG];
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
@@ -129,20 +143,18 @@ struct EpiGnSilu {
         mean[g] = m;
         rstd[g] = 1.0f / sqrtf(qs * (1.0f / GW) + GN_EPS);
       }
-      if (!prow) continue;
-      float* orow = a.out + (size_t)p * a.ldo;
+      float* orow = a.out + (size_t)pc * a.ldo;
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int f = fw + 32 * fb + 8 * q + 4 * h;
-          if (f >= F) continue;
           const int g = (fb * 16 + 4 * q) / RPG;
-          const float4 gv = ld4g(a.gamma, f, F), bev = ld4g(a.beta, f, F);
-          float4 z = make_float4(acc[fb][pb][4 * q], acc[fb][pb][4 * q + 1], acc[fb][pb][4 * q + 2], acc[fb][pb][4 * q + 3]);
-          if (a.z_out) {
-            st4g(a.z_out + (size_t)p * a.ldz, f, F, z);
-            if ((f % GW) == 0) {   // first quad of the group in this lane-pair writes the stats
+          const float4 gv = ldq<FAST>(a.gamma, f, F), bev = ldq<FAST>(a.beta, f, F);
+          const float4 z = make_float4(acc[fb][pb][4 * q], acc[fb][pb][4 * q + 1], acc[fb][pb][4 * q + 2], acc[fb][pb][4 * q + 3]);
+          if (a.z_out && prow) {
+            stq<FAST>(a.z_out + (size_t)p * a.ldz, f, F, z);
+            if ((f % GW) == 0 && f < F) {   // first quad of the group in this lane-pair writes the stats
               float* sp = a.stats + ((size_t)p * (F / GW) + f / GW) * 2;
               sp[0] = mean[g]; sp[1] = rstd[g];
             }
@@ -153,7 +165,7 @@ struct EpiGnSilu {
           y.z = silu_f((z.z - mean[g]) * rstd[g] * gv.z + bev.z);
           y.w = silu_f((z.w - mean[g]) * rstd[g] * gv.w + bev.w);
           if (DROP && a.drop_mode == 1) {
-            const float4 mk = ld4g(a.mask + (size_t)p * a.ldm, f, F);
+            const float4 mk = ldq<FAST>(a.mask + (size_t)pc * a.ldm, f, F);
             y.x *= mk.x * a.keep_scale; y.y *= mk.y * a.keep_scale; y.z *= mk.z * a.keep_scale; y.w *= mk.w * a.keep_scale;
           } else if (DROP && a.drop_mode == 2) {
             const uint32_t step = a.step_dev ? (uint32_t)*a.step_dev : a.step;
@@ -163,7 +175,7 @@ struct EpiGnSilu {
             y.z *= (u01(r.z) >= a.p_drop) ? a.keep_scale : 0.f;
             y.w *= (u01(r.w) >= a.p_drop) ? a.keep_scale : 0.f;
           }
-          st4g(orow, f, F, y);
+          if (prow) stq<FAST>(orow, f, F, y);
         }
     }
   }
@@ -171,8 +183,8 @@ struct EpiGnSilu {
 
 // ---- output_proj fused with the DDPM posterior update (models/diffusion.py:398-425) ----
 // eps = acc + bias;  x0 = (x - c0*eps)/c1;  t>0: x' = (c2*x0/c3 + c4*x/c3) + c5*z;  t==0: x' = x0
-// Evaluated with explicitly rounded mul/add/div in the reference's op order (no FMA
-// contraction), so that given the same eps the update is bit-identical to torch's.
+// Evaluated in the reference's op order with one rounding per operation (the library is built
+// with -ffp-contract=off), so given the same eps the update is bit-identical to torch's.
 struct EpiPosterior {
   struct Args {
     const float* bias;
@@ -180,12 +192,16 @@ struct EpiPosterior {
     float* xout; int ldo;
     const float* coef;              // dev [T][6]
     const int* t_dev; int t_imm;
-    const float* z; int ldzz;       // injected noise for draw 0 (t = T-1), [P][F]; null -> Philox
+    const float* z; int ldzz;       // injected noise for draw 0 (t = t_first), [P][F]; null -> Philox
     long long z_step_stride; int t_first;   // draw for step t sits at z + (t_first - t) * stride
     uint64_t seed; uint32_t row_offset;
     float* mut_mask; int mutation_dim;   // written at t == 0 when non-null: (x' > 0.5)
   };
-  template <int NFB, int NPB>
+  static bool fast_ok(const Args& a, int F) {
+    return F % 4 == 0 && al16(a.bias) && al16(a.xin) && al16(a.xout) && a.ldx % 4 == 0 && a.ldo % 4 == 0 &&
+           (!a.z || (al16(a.z) && a.ldzz % 4 == 0 && a.z_step_stride % 4 == 0));
+  }
+  template <int NFB, int NPB, bool FAST>
   static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, int fw, int pw, int lane, int F, int P) {
     const int l31 = lane & 31, h = lane >> 5;
     const int t = a.t_dev ? *a.t_dev : a.t_imm;
@@ -195,34 +211,35 @@ struct EpiPosterior {
     OSD_FOR_QUADS(fb, pb, q) {
       const int f = fw + 32 * fb + 8 * q + 4 * h;
       const int p = pw + 32 * pb + l31;
-      if (p >= P || f >= F) continue;
-      const float4 bv = ld4g(a.bias, f, F);
-      const float4 x = ld4g(a.xin + (size_t)p * a.ldx, f, F);
+      const int pc = p < P ? p : P - 1;
+      const bool ok = p < P && f < F;
+      const float4 bv = ldq<FAST>(a.bias, f, F);
+      const float4 x = ldq<FAST>(a.xin + (size_t)pc * a.ldx, f, F);
       const float e[4] = {acc[fb][pb][4 * q] + bv.x, acc[fb][pb][4 * q + 1] + bv.y, acc[fb][pb][4 * q + 2] + bv.z, acc[fb][pb][4 * q + 3] + bv.w};
       const float xv[4] = {x.x, x.y, x.z, x.w};
       float o[4];
       if (t > 0) {
         float4 zz;
-        if (zbase) zz = ld4g(zbase + (size_t)p * a.ldzz, f, F);
+        if (zbase) zz = ldq<FAST>(zbase + (size_t)pc * a.ldzz, f, F);
         else zz = randn4(a.seed, a.row_offset + (uint32_t)p, (uint32_t)(f >> 2), (uint32_t)t, TAG_POSTERIOR);
         const float zv[4] = {zz.x, zz.y, zz.z, zz.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float x0 = __fdiv_rn(__fsub_rn(xv[r], __fmul_rn(c0, e[r])), c1);
-          const float m = __fadd_rn(__fdiv_rn(__fmul_rn(c2, x0), c3), __fdiv_rn(__fmul_rn(c4, xv[r]), c3));
-          o[r] = __fadd_rn(m, __fmul_rn(c5, zv[r]));
+          const float x0 = (xv[r] - c0 * e[r]) / c1;
+          const float m = c2 * x0 / c3 + c4 * xv[r] / c3;
+          o[r] = m + c5 * zv[r];
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = __fdiv_rn(__fsub_rn(xv[r], __fmul_rn(c0, e[r])), c1);
-        if (a.mut_mask && f < a.mutation_dim) {
+        for (int r = 0; r < 4; ++r) o[r] = (xv[r] - c0 * e[r]) / c1;
+        if (a.mut_mask && ok && f < a.mutation_dim) {
           float* mrow = a.mut_mask + (size_t)p * a.mutation_dim;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (f + r < a.mutation_dim) mrow[f + r] = (o[r] > 0.5f) ? 1.0f : 0.0f;
         }
       }
-      st4g(a.xout + (size_t)p * a.ldo, f, F, make_float4(o[0], o[1], o[2], o[3]));
+      if (p < P) stq<FAST>(a.xout + (size_t)pc * a.ldo, f, F, make_float4(o[0], o[1], o[2], o[3]));
     }
   }
 };
@@ -237,24 +254,30 @@ struct EpiMse {
     float* loss;                  // dev float[1], atomically accumulated
     float inv_count; float gscale;
   };
-  template <int NFB, int NPB>
+  static bool fast_ok(const Args& a, int F) {
+    return F % 4 == 0 && al16(a.bias) && al16(a.noise) && a.ldn % 4 == 0 && (!a.dout || (al16(a.dout) && a.ldd % 4 == 0)) &&
+           (!a.pred || (al16(a.pred) && a.ldp % 4 == 0));
+  }
+  template <int NFB, int NPB, bool FAST>
   static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, int fw, int pw, int lane, int F, int P) {
     const int l31 = lane & 31, h = lane >> 5;
     float part = 0.f;
     OSD_FOR_QUADS(fb, pb, q) {
       const int f = fw + 32 * fb + 8 * q + 4 * h;
       const int p = pw + 32 * pb + l31;
-      if (p >= P || f >= F) continue;
-      const float4 bv = ld4g(a.bias, f, F);
-      const float4 nz = ld4g(a.noise + (size_t)p * a.ldn, f, F);
-      float4 e = make_float4(acc[fb][pb][4 * q] + bv.x, acc[fb][pb][4 * q + 1] + bv.y, acc[fb][pb][4 * q + 2] + bv.z, acc[fb][pb][4 * q + 3] + bv.w);
-      if (a.pred) st4g(a.pred + (size_t)p * a.ldp, f, F, e);
+      const int pc = p < P ? p : P - 1;
+      const bool prow = p < P;
+      const float4 bv = ldq<FAST>(a.bias, f, F);
+      const float4 nz = ldq<FAST>(a.noise + (size_t)pc * a.ldn, f, F);
+      const float4 e = make_float4(acc[fb][pb][4 * q] + bv.x, acc[fb][pb][4 * q + 1] + bv.y, acc[fb][pb][4 * q + 2] + bv.z, acc[fb][pb][4 * q + 3] + bv.w);
+      if (a.pred && prow) stq<FAST>(a.pred + (size_t)p * a.ldp, f, F, e);
       float4 d = make_float4(e.x - nz.x, e.y - nz.y, e.z - nz.z, e.w - nz.w);
-      if (f + 1 >= F) d.y = 0.f;
-      if (f + 2 >= F) d.z = 0.f;
-      if (f + 3 >= F) d.w = 0.f;
+      if (!prow || f >= F) d.x = 0.f;
+      if (!prow || f + 1 >= F) d.y = 0.f;
+      if (!prow || f + 2 >= F) d.z = 0.f;
+      if (!prow || f + 3 >= F) d.w = 0.f;
       part += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
-      if (a.dout) st4g(a.dout + (size_t)p * a.ldd, f, F, make_float4(d.x * a.gscale, d.y * a.gscale, d.z * a.gscale, d.w * a.gscale));
+      if (a.dout && prow) stq<FAST>(a.dout + (size_t)p * a.ldd, f, F, make_float4(d.x * a.gscale, d.y * a.gscale, d.z * a.gscale, d.w * a.gscale));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);

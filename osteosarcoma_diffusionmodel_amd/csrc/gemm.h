@@ -73,32 +73,78 @@ __device__ __forceinline__ void st4g(float* row, int i, int n, float4 v) {
   if (i + 3 < n) p[3] = v.w;
 }
 
+// FAST = every pointer 16-byte aligned, leading dimensions and extents multiples of 4: loads
+// become unconditional float4 loads from a clamped (always valid) address with the value
+// zeroed by a select, so the compiler can keep a whole tile of loads in flight instead of
+// waiting behind each guarded load.
+template <bool FAST>
+__device__ __forceinline__ float4 ldq(const float* v, int i, int n) {
+  if constexpr (FAST) {
+    const int ic = (i < n - 4) ? i : n - 4;
+    const float4 r = *reinterpret_cast<const float4*>(v + ic);
+    const bool ok = i < n;
+    return make_float4(ok ? r.x : 0.f, ok ? r.y : 0.f, ok ? r.z : 0.f, ok ? r.w : 0.f);
+  } else {
+    return ld4g(v, i, n);
+  }
+}
+// FAST staging load: v[min(i, n-4) .. +3], no zeroing.  Out-of-range chunks re-read valid
+// (finite) data; the kernel zeroes the K tail of the A operand when it writes LDS, and rows or
+// features beyond the extents only ever feed accumulators that are never stored.
+__device__ __forceinline__ float4 ldraw(const float* v, int i, int n) {
+  const int ic = (i < n - 4) ? i : n - 4;
+  return *reinterpret_cast<const float4*>(v + ic);
+}
+template <bool FAST>
+__device__ __forceinline__ void stq(float* row, int i, int n, float4 v) {
+  if constexpr (FAST) {
+    if (i < n) *reinterpret_cast<float4*>(row + i) = v;
+  } else {
+    st4g(row, i, n, v);
+  }
+}
+
 // ---- global -> register staging of one BK-deep tile ------------------------------
 // KC operand, R rows: thread owns k-chunk kc = tid&7 of rows (tid>>3) + 32*i.
 template <int R>
 struct StageKC {
   static constexpr int N = R / 32;
   float4 v[N];
+  template <bool FAST>
   __device__ __forceinline__ void load(const GemmArgs& g, bool isB, int r0, int nrows, int k0, int tid) {
     const int kc = tid & 7;
     int k = k0 + 4 * kc;
     const float* base; int ld; int kend;
     if (isB) {
-      if (k < g.K0) { base = g.B0; ld = g.ldb0; kend = (g.K0 < g.K ? g.K0 : g.K); }
+      // FAST: K0 is a multiple of BK (or >= K), so the panel choice is uniform over the tile
+      const bool first = FAST ? (k0 < g.K0) : (k < g.K0);
+      if (first) { base = g.B0; ld = g.ldb0; kend = (g.K0 < g.K ? g.K0 : g.K); }
       else { base = g.B1; ld = g.ldb1; kend = g.K - g.K0; k -= g.K0; }
     } else { base = g.A; ld = g.lda; kend = g.K; }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int row = r0 + (tid >> 3) + 32 * i;
-      if (row < nrows && k < kend) v[i] = ld4g(base + (size_t)row * ld, k, kend);
-      else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (FAST) {
+        // clamped, unconditional: out-of-range rows / k re-read valid data (see ldraw)
+        const int rc = (row < nrows) ? row : nrows - 1;
+        v[i] = ldraw(base + (size_t)rc * ld, k, kend);
+      } else {
+        if (row < nrows && k < kend) v[i] = ld4g(base + (size_t)row * ld, k, kend);
+        else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   }
-  __device__ __forceinline__ void store(float* lds, int tid) const {
+  // kvalid = number of in-range k of this tile; chunks at or beyond it are stored as zeros
+  // (only needed for ONE operand: 0 * finite = 0).  Pass BK to skip the zeroing.
+  __device__ __forceinline__ void store(float* lds, int tid, int kvalid) const {
     const int kc = tid & 7;
+    const bool ok = 4 * kc < kvalid;
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-      *reinterpret_cast<float4*>(&lds[((tid >> 3) + 32 * i) * LDK + 4 * kc]) = v[i];
+    for (int i = 0; i < N; ++i) {
+      const float4 t = v[i];
+      *reinterpret_cast<float4*>(&lds[((tid >> 3) + 32 * i) * LDK + 4 * kc]) =
+          make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+    }
   }
 };
 // NKC operand, tile [BK][R]: chunk c = tid + 256*i -> k = c / (R/4), rc = c % (R/4).
@@ -108,28 +154,37 @@ struct StageNK {
   static constexpr int N = (BK * CPR) / NTHREADS;
   static_assert(N >= 1, "tile too small");
   float4 v[N];
+  template <bool FAST>
   __device__ __forceinline__ void load(const float* base, int ld, int r0, int nrows, int k0, int K, int tid) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int c = tid + NTHREADS * i;
       const int k = k0 + c / CPR;
       const int r = r0 + 4 * (c % CPR);
-      if (k < K && r < nrows) v[i] = ld4g(base + (size_t)k * ld, r, nrows);
-      else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (FAST) {
+        const int kc = (k < K) ? k : K - 1;
+        v[i] = ldraw(base + (size_t)kc * ld, r, nrows);
+      } else {
+        if (k < K && r < nrows) v[i] = ld4g(base + (size_t)k * ld, r, nrows);
+        else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   }
-  __device__ __forceinline__ void store(float* lds, int tid) const {
+  __device__ __forceinline__ void store(float* lds, int tid, int kvalid) const {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int c = tid + NTHREADS * i;
-      *reinterpret_cast<float4*>(&lds[(c / CPR) * R + 4 * (c % CPR)]) = v[i];
+      const bool ok = (c / CPR) < kvalid;
+      const float4 t = v[i];
+      *reinterpret_cast<float4*>(&lds[(c / CPR) * R + 4 * (c % CPR)]) =
+          make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
     }
   }
 };
 
 // ---- the kernel -----------------------------------------------------------------
-// Epi::apply(acc, args, f_wave, p_wave, lane, F, P) consumes the wave's accumulators.
-template <class T, bool AKC, bool BKC, class Epi>
+// Epi::apply<NFB,NPB,FAST>(acc, args, f_wave, p_wave, lane, F, P) consumes the wave's accumulators.
+template <class T, bool AKC, bool BKC, class Epi, bool FAST>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g, typename Epi::Args ea) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As0 = smem;
@@ -167,14 +222,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g, typename 
   StageKC<T::BP> sBk; StageNK<T::BP> sBn;
 
   auto gload = [&](int k0) {
-    if constexpr (AKC) sAk.load(g, false, f0, g.F, k0, tid);
-    else sAn.load(g.A, g.lda, f0, g.F, k0, g.K, tid);
-    if constexpr (BKC) sBk.load(g, true, p0, g.P, k0, tid);
-    else sBn.load(g.B0, g.ldb0, p0, g.P, k0, g.K, tid);
+    if constexpr (AKC) sAk.template load<FAST>(g, false, f0, g.F, k0, tid);
+    else sAn.template load<FAST>(g.A, g.lda, f0, g.F, k0, g.K, tid);
+    if constexpr (BKC) sBk.template load<FAST>(g, true, p0, g.P, k0, tid);
+    else sBn.template load<FAST>(g.B0, g.ldb0, p0, g.P, k0, g.K, tid);
   };
-  auto lstore = [&](float* As, float* Bs) {
-    if constexpr (AKC) sAk.store(As, tid); else sAn.store(As, tid);
-    if constexpr (BKC) sBk.store(Bs, tid); else sBn.store(Bs, tid);
+  auto lstore = [&](float* As, float* Bs, int k0) {
+    const int kvalid = FAST ? g.K - k0 : BK;     // slow path zero-fills at load time
+    if constexpr (AKC) sAk.store(As, tid, kvalid); else sAn.store(As, tid, kvalid);
+    if constexpr (BKC) sBk.store(Bs, tid, BK); else sBn.store(Bs, tid, BK);
   };
   auto compute = [&](const float* As, const float* Bs) {
 #pragma unroll
@@ -212,7 +268,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g, typename 
 
   const int nk = (g.K + BK - 1) / BK;
   gload(0);
-  lstore(As0, Bs0);
+  lstore(As0, Bs0, 0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = (kt + 1 < nk);
@@ -222,11 +278,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g, typename 
     float* Bn = (kt & 1) ? Bs0 : Bs1;
     if (more) gload((kt + 1) * BK);
     compute(Ac, Bc);
-    if (more) lstore(An, Bn);
+    if (more) lstore(An, Bn, (kt + 1) * BK);
     __syncthreads();
   }
 
-  Epi::template apply<T::NFB, T::NPB>(acc, ea, f0 + wf, p0 + wp, lane, g.F, g.P);
+  Epi::template apply<T::NFB, T::NPB, FAST>(acc, ea, f0 + wf, p0 + wp, lane, g.F, g.P);
 }
 
 // element (fb, reg) of a lane's fragment is feature  f_wave + 32*fb + 8*(reg>>2) + 4*h + (reg&3)

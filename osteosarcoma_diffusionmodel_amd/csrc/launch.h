@@ -26,22 +26,44 @@ struct KernelReg { const void* fn; int lds_bytes; };
 std::vector<KernelReg>& kernel_registry();
 hipError_t prepare_kernels();
 
-template <class T, bool AKC, bool BKC, class Epi>
+template <class T, bool AKC, bool BKC, class Epi, bool FAST>
 struct GemmRegistrar {
-  GemmRegistrar() { kernel_registry().push_back({reinterpret_cast<const void*>(gemm_kernel<T, AKC, BKC, Epi>), T::LDS_BYTES}); }
+  GemmRegistrar() { kernel_registry().push_back({reinterpret_cast<const void*>(gemm_kernel<T, AKC, BKC, Epi, FAST>), T::LDS_BYTES}); }
   static GemmRegistrar instance;
 };
-template <class T, bool AKC, bool BKC, class Epi>
-GemmRegistrar<T, AKC, BKC, Epi> GemmRegistrar<T, AKC, BKC, Epi>::instance;
+template <class T, bool AKC, bool BKC, class Epi, bool FAST>
+GemmRegistrar<T, AKC, BKC, Epi, FAST> GemmRegistrar<T, AKC, BKC, Epi, FAST>::instance;
 
-template <class T, bool AKC, bool BKC, class Epi>
-hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, const typename Epi::Args& ea) {
-  (void)&GemmRegistrar<T, AKC, BKC, Epi>::instance;   // odr-use: forces the registration
-  auto kern = gemm_kernel<T, AKC, BKC, Epi>;
-  if (g.F <= 0 || g.P <= 0) return hipSuccess;
+inline bool ptr_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Preconditions of the branch-free (FAST) operand loads, see gemm.h.
+inline bool gemm_fast_ok(const GemmArgs& g, bool a_kc, bool b_kc) {
+  if (!ptr_al16(g.A) || !ptr_al16(g.B0) || g.lda % 4 || g.ldb0 % 4 || g.K < 4) return false;
+  const bool two = b_kc && g.K0 < g.K;
+  if (a_kc) { if (g.K % 4) return false; } else { if (g.F % 4 || g.F < 4) return false; }
+  if (b_kc) {
+    if (g.K % 4) return false;
+    if (two && (g.K0 % BK || (g.K - g.K0) % 4 || g.K - g.K0 < 4 || !ptr_al16(g.B1) || g.ldb1 % 4)) return false;
+  } else {
+    if (g.P % 4 || g.P < 4) return false;
+  }
+  return true;
+}
+
+template <class T, bool AKC, bool BKC, class Epi, bool FAST>
+hipError_t launch_gemm_v(hipStream_t s, const GemmArgs& g, const typename Epi::Args& ea) {
+  (void)&GemmRegistrar<T, AKC, BKC, Epi, FAST>::instance;   // odr-use: forces the registration
+  auto kern = gemm_kernel<T, AKC, BKC, Epi, FAST>;
   const int grid = gemm_grid(g.F, g.P, T::BF, T::BP);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), T::LDS_BYTES, s, g, ea);
   return hipGetLastError();
+}
+
+template <class T, bool AKC, bool BKC, class Epi>
+hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, const typename Epi::Args& ea) {
+  if (g.F <= 0 || g.P <= 0) return hipSuccess;
+  if (gemm_fast_ok(g, AKC, BKC) && Epi::fast_ok(ea, g.F)) return launch_gemm_v<T, AKC, BKC, Epi, true>(s, g, ea);
+  return launch_gemm_v<T, AKC, BKC, Epi, false>(s, g, ea);
 }
 
 }  // namespace osd
