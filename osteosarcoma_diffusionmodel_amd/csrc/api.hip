@@ -153,10 +153,10 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
   const int n = (int)in.n;
   {
     GemmArgs g{};
-    g.A = h->params[pm.in_w]; g.lda = a.D; g.B0 = in.x; g.ldb0 = in.ldx; g.K0 = a.D;
+    g.A = h->w_in_packed; g.lda = h->w_in_ld; g.B0 = in.x; g.ldb0 = in.ldx; g.K0 = a.D;
     g.F = a.H0; g.P = n; g.K = a.D;
     EpiInput::Args ea{h->params[pm.in_b], h->d_temb, a.H0, in.t_index, in.t_dev, in.t_imm, ws.cproj, a.H0, ws.h0, a.H0};
-    OSD_HIP(launch_input(s, g, ea));
+    OSD_HIP(launch_input(s, g, ea, true));
     OSD_TRY(prof_mark(h, s));
   }
   const float* cur = ws.h0;
@@ -200,6 +200,19 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
     cur = ws.out[b];
     cur_w = l2.N;
   }
+  return OSD_OK;
+}
+
+// Derived copies that follow the current parameters: the t_emb table time_proj(TimeEmbedding(t/T))
+// (models/diffusion.py:222-223; all rows of a sampling step share t and training rows gather their
+// t, so the Linear runs T times, not B) and the zero-padded input_proj.weight.
+int refresh_derived(osd_handle* h, hipStream_t s) {
+  const Arch& a = h->arch;
+  GemmArgs g{};
+  g.A = h->params[a.pm.tp_w]; g.lda = a.time_dim; g.B0 = h->d_time_emb; g.ldb0 = a.time_dim; g.K0 = a.time_dim;
+  g.F = a.H0; g.P = a.T; g.K = a.time_dim;
+  OSD_HIP(launch_linear(s, g, true, true, h->params[a.pm.tp_b], h->d_temb, a.H0, false, false));
+  OSD_HIP(launch_copy2d(s, h->params[a.pm.in_w], a.D, h->w_in_packed, h->w_in_ld, a.H0, a.D));   // pad columns stay zero
   return OSD_OK;
 }
 
@@ -266,9 +279,12 @@ int osd_create(const osd_config* cfg, osd_handle** out) {
   const int T = a.T;
   OSD_HIP(hipMalloc((void**)&h->d_sqrt_ac, T * 4));
   OSD_HIP(hipMalloc((void**)&h->d_sqrt_1m, T * 4));
-  OSD_HIP(hipMalloc((void**)&h->d_coef, (size_t)T * 6 * 4));
+  OSD_HIP(hipMalloc((void**)&h->d_coef, (size_t)T * 4 * 4));
   OSD_HIP(hipMalloc((void**)&h->d_time_emb, (size_t)T * a.time_dim * 4));
   OSD_HIP(hipMalloc((void**)&h->d_temb, (size_t)T * a.H0 * 4));
+  h->w_in_ld = (a.D + BK - 1) / BK * BK;
+  OSD_HIP(hipMalloc((void**)&h->w_in_packed, (size_t)a.H0 * h->w_in_ld * 4));
+  OSD_HIP(hipMemset(h->w_in_packed, 0, (size_t)a.H0 * h->w_in_ld * 4));
   OSD_HIP(hipMalloc((void**)&h->main.t_dev, 64));
   OSD_HIP(hipMalloc((void**)&h->loss_dev, 64));
   OSD_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
@@ -294,7 +310,7 @@ int osd_destroy(osd_handle* h) {
   e = hipDeviceSynchronize();
   for (auto& s : h->slots) free_slot(s, true);
   free_slot(h->main, false);
-  float* bufs[] = {h->d_sqrt_ac, h->d_sqrt_1m, h->d_coef, h->d_time_emb, h->d_temb, h->train_arena, h->loss_dev};
+  float* bufs[] = {h->w_in_packed, h->d_sqrt_ac, h->d_sqrt_1m, h->d_coef, h->d_time_emb, h->d_temb, h->train_arena, h->loss_dev};
   for (float* p : bufs) if (p) e = hipFree(p);
   if (h->normsq_dev) e = hipFree(h->normsq_dev);
   if (h->fork_ev) e = hipEventDestroy(h->fork_ev);
@@ -331,7 +347,24 @@ int osd_set_schedule(osd_handle* h, const float* sqrt_ac, const float* sqrt_1m_a
   OSD_HIP(hipSetDevice(h->cfg.device));
   OSD_HIP(hipMemcpy(h->d_sqrt_ac, sqrt_ac, a.T * 4, hipMemcpyHostToDevice));
   OSD_HIP(hipMemcpy(h->d_sqrt_1m, sqrt_1m_ac, a.T * 4, hipMemcpyHostToDevice));
-  OSD_HIP(hipMemcpy(h->d_coef, post_coef, (size_t)a.T * 6 * 4, hipMemcpyHostToDevice));
+  {
+    // fold the reference's six per-step scalars into x' = A*x + B*eps + C*z (see EpiPosterior)
+    std::vector<float> abc((size_t)a.T * 4, 0.f);
+    for (int t = 0; t < a.T; ++t) {
+      const double c0 = post_coef[6 * t], c1 = post_coef[6 * t + 1], c2 = post_coef[6 * t + 2], c3 = post_coef[6 * t + 3],
+                   c4 = post_coef[6 * t + 4], c5 = post_coef[6 * t + 5];
+      if (t > 0) {
+        abc[4 * t] = (float)(c4 / c3 + c2 / (c1 * c3));
+        abc[4 * t + 1] = (float)(-c0 * c2 / (c1 * c3));
+        abc[4 * t + 2] = (float)c5;
+      } else {
+        abc[0] = (float)(1.0 / c1);
+        abc[1] = (float)(-c0 / c1);
+        abc[2] = 0.f;
+      }
+    }
+    OSD_HIP(hipMemcpy(h->d_coef, abc.data(), abc.size() * 4, hipMemcpyHostToDevice));
+  }
   OSD_HIP(hipMemcpy(h->d_time_emb, time_emb, (size_t)a.T * a.time_dim * 4, hipMemcpyHostToDevice));
   h->have_schedule = true;
   return OSD_OK;
@@ -346,12 +379,7 @@ int osd_load_weights(osd_handle* h, const float* const* params, int n) {
     if (!params[i]) { set_error("parameter %d is null", i); return OSD_EINVAL; }
   OSD_HIP(hipSetDevice(h->cfg.device));
   h->params.assign(params, params + n);
-  // t_emb table: time_proj(TimeEmbedding(t/T)) for every t (models/diffusion.py:222-223); all rows
-  // of a sampling step share t and training rows gather their t, so the Linear runs T times, not B.
-  GemmArgs g{};
-  g.A = h->params[a.pm.tp_w]; g.lda = a.time_dim; g.B0 = h->d_time_emb; g.ldb0 = a.time_dim; g.K0 = a.time_dim;
-  g.F = a.H0; g.P = a.T; g.K = a.time_dim;
-  OSD_HIP(launch_linear(h->stream, g, true, true, h->params[a.pm.tp_b], h->d_temb, a.H0, false, false));
+  OSD_TRY(refresh_derived(h, h->stream));
   h->have_weights = true;
   return OSD_OK;
 }
@@ -495,8 +523,11 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
   if (!cond || !x_out) { set_error("null tensor"); return OSD_EINVAL; }
   if (n == 0) return OSD_OK;
   OSD_HIP(hipSetDevice(h->cfg.device));
-  const int64_t chunk = std::min<int64_t>(h->chunk_rows, n);
-  const int64_t n_chunks = (n + chunk - 1) / chunk;
+  // equal chunks (rounded up to whole 128-row tiles) of at most chunk_rows rows
+  int64_t n_chunks = (n + h->chunk_rows - 1) / h->chunk_rows;
+  int64_t chunk = ((n + n_chunks - 1) / n_chunks + 127) / 128 * 128;
+  if (chunk > n) chunk = n;
+  n_chunks = (n + chunk - 1) / chunk;
   const int n_slots = (int)std::min<int64_t>(h->n_streams, n_chunks);
   while ((int)h->slots.size() < n_slots) {
     Slot sl;

@@ -232,53 +232,60 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g, typename 
     if constexpr (AKC) sAk.store(As, tid, kvalid); else sAn.store(As, tid, kvalid);
     if constexpr (BKC) sBk.store(Bs, tid, BK); else sBn.store(Bs, tid, BK);
   };
-  auto compute = [&](const float* As, const float* Bs) {
+  // one quarter (8 of the 32 k) of a staged tile: 4 LDS fragment reads, 16 * NFB * NPB / 4 MFMAs
+  auto compute = [&](const float* As, const float* Bs, int i) {
+    float a[T::NFB][4], bb[T::NPB][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float a[T::NFB][4], bb[T::NPB][4];
+    for (int fb = 0; fb < T::NFB; ++fb) {
+      if constexpr (AKC) {
+        const float4 t = *reinterpret_cast<const float4*>(&As[(wf + 32 * fb + l31) * LDK + 8 * i + 4 * h]);
+        a[fb][0] = t.x; a[fb][1] = t.y; a[fb][2] = t.z; a[fb][3] = t.w;
+      } else {
 #pragma unroll
-      for (int fb = 0; fb < T::NFB; ++fb) {
-        if constexpr (AKC) {
-          const float4 t = *reinterpret_cast<const float4*>(&As[(wf + 32 * fb + l31) * LDK + 8 * i + 4 * h]);
-          a[fb][0] = t.x; a[fb][1] = t.y; a[fb][2] = t.z; a[fb][3] = t.w;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) a[fb][e] = As[(8 * i + 4 * h + e) * T::BF + wf + 32 * fb + l31];
-        }
+        for (int e = 0; e < 4; ++e) a[fb][e] = As[(8 * i + 4 * h + e) * T::BF + wf + 32 * fb + l31];
       }
-#pragma unroll
-      for (int pb = 0; pb < T::NPB; ++pb) {
-        if constexpr (BKC) {
-          const float4 t = *reinterpret_cast<const float4*>(&Bs[(wp + 32 * pb + l31) * LDK + 8 * i + 4 * h]);
-          bb[pb][0] = t.x; bb[pb][1] = t.y; bb[pb][2] = t.z; bb[pb][3] = t.w;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bb[pb][e] = Bs[(8 * i + 4 * h + e) * T::BP + wp + 32 * pb + l31];
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int fb = 0; fb < T::NFB; ++fb)
-#pragma unroll
-          for (int pb = 0; pb < T::NPB; ++pb)
-            acc[fb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fb][e], bb[pb][e], acc[fb][pb], 0, 0, 0);
     }
+#pragma unroll
+    for (int pb = 0; pb < T::NPB; ++pb) {
+      if constexpr (BKC) {
+        const float4 t = *reinterpret_cast<const float4*>(&Bs[(wp + 32 * pb + l31) * LDK + 8 * i + 4 * h]);
+        bb[pb][0] = t.x; bb[pb][1] = t.y; bb[pb][2] = t.z; bb[pb][3] = t.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bb[pb][e] = Bs[(8 * i + 4 * h + e) * T::BP + wp + 32 * pb + l31];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int fb = 0; fb < T::NFB; ++fb)
+#pragma unroll
+        for (int pb = 0; pb < T::NPB; ++pb)
+          acc[fb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fb][e], bb[pb][e], acc[fb][pb], 0, 0, 0);
   };
 
+  // Software pipeline, two LDS buffers, register prefetch two tiles ahead:
+  //   iteration kt computes on LDS tile kt, writes register tile kt+1 into the other buffer and
+  //   issues the global loads of tile kt+2 -- both placed BETWEEN MFMA groups so they issue in the
+  //   shadow of the matrix pipe; one barrier per iteration publishes tile kt+1.
+  // (writing buffer (kt+1)&1 during iteration kt is safe: its tile kt-1 was last read in
+  //  iteration kt-1, which every wave left through the barrier.)
   const int nk = (g.K + BK - 1) / BK;
   gload(0);
   lstore(As0, Bs0, 0);
+  if (nk > 1) gload(BK);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1 < nk);
     float* Ac = (kt & 1) ? As1 : As0;
     float* Bc = (kt & 1) ? Bs1 : Bs0;
     float* An = (kt & 1) ? As0 : As1;
     float* Bn = (kt & 1) ? Bs0 : Bs1;
-    if (more) gload((kt + 1) * BK);
-    compute(Ac, Bc);
-    if (more) lstore(An, Bn, (kt + 1) * BK);
+    compute(Ac, Bc, 0);
+    if (kt + 1 < nk) lstore(An, Bn, (kt + 1) * BK);
+    compute(Ac, Bc, 1);
+    if (kt + 2 < nk) gload((kt + 2) * BK);
+    compute(Ac, Bc, 2);
+    compute(Ac, Bc, 3);
     __syncthreads();
   }
 

@@ -88,8 +88,10 @@ struct osd_handle {
   hipStream_t stream = nullptr;
   std::vector<const float*> params;
   bool have_schedule = false, have_weights = false;
+  float* w_in_packed = nullptr;      // input_proj.weight zero-padded to [H0][roundup(D,32)] for the LDS-DMA kernel
+  int w_in_ld = 0;
   float *d_sqrt_ac = nullptr, *d_sqrt_1m = nullptr, *d_coef = nullptr, *d_time_emb = nullptr, *d_temb = nullptr;
-  int64_t chunk_rows = 32768;
+  int64_t chunk_rows = 65536;
   int n_streams = 2;
   std::vector<osd::Slot> slots;
   osd::Slot main;            // workspace used by the single-stream entry points

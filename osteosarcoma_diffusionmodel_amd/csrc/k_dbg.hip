@@ -1,0 +1,98 @@
+// k_dbg.hip -- micro-benchmark of the GEMM inner loop (diagnostic entry point, not in osdiff.h):
+// isolates what the matrix pipe sustains with / without LDS fragment reads, barriers and DMA.
+#include "handle.h"
+#include "gemm_glds.h"
+
+namespace osd {
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_mfma_rate(const float* src, float* dst, int nk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wf = (wave >> 1) * 64, wp = (wave & 1) * 64;
+  for (int i = tid; i < 16384; i += 256) smem[i] = (float)((i * 7) % 13) * 0.01f;
+  __syncthreads();
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float* As0 = smem; float* As1 = smem + 4096; float* Bs0 = smem + 8192; float* Bs1 = smem + 12288;
+  int a_rd[2], a_sw[2], b_rd[2], b_sw[2];
+  for (int fb = 0; fb < 2; ++fb) { const int R = wf + 32 * fb + l31; a_rd[fb] = R * 32; a_sw[fb] = h ^ ((R >> 1) & 7); }
+  for (int pb = 0; pb < 2; ++pb) { const int R = wp + 32 * pb + l31; b_rd[pb] = R * 32; b_sw[pb] = h ^ ((R >> 1) & 7); }
+  float ra[2][4], rb[2][4];
+  for (int i = 0; i < 2; ++i) for (int e = 0; e < 4; ++e) { ra[i][e] = 0.001f * (lane + e + i); rb[i][e] = 0.002f * (lane - e + i); }
+  const float* gbase = src + (size_t)(blockIdx.x % 64) * 4096 + (wave * 64 + lane) * 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* Ac = (kt & 1) ? As1 : As0;
+    const float* Bc = (kt & 1) ? Bs1 : Bs0;
+    if (MODE >= 3) {
+      const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr((kt & 1) ? As0 : As1) + (unsigned)wave * 1024u);
+      const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr((kt & 1) ? Bs0 : Bs1) + (unsigned)wave * 1024u);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { glds16(gbase + j * 1024, la + j * 4096u); glds16(gbase + 8192 + j * 1024, lb + j * 4096u); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a[2][4], bb[2][4];
+      if (MODE >= 1) {
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) { const float4 t = *reinterpret_cast<const float4*>(&Ac[a_rd[fb] + 4 * (a_sw[fb] ^ (2 * i))]); a[fb][0] = t.x; a[fb][1] = t.y; a[fb][2] = t.z; a[fb][3] = t.w; }
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) { const float4 t = *reinterpret_cast<const float4*>(&Bc[b_rd[pb] + 4 * (b_sw[pb] ^ (2 * i))]); bb[pb][0] = t.x; bb[pb][1] = t.y; bb[pb][2] = t.z; bb[pb][3] = t.w; }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) for (int e = 0; e < 4; ++e) { a[q][e] = ra[q][e]; bb[q][e] = rb[q][e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) acc[fb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fb][e], bb[pb][e], acc[fb][pb], 0, 0, 0);
+    }
+    if (MODE >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (MODE >= 2) __syncthreads();
+  }
+  float s = 0.f;
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  dst[blockIdx.x * 256 + tid] = s;
+}
+
+}  // namespace osd
+
+using namespace osd;
+
+extern "C" int osd_dbg_mfma_rate(osd_handle* h, int mode, int nk, int grid, const float* src, float* dst, float* ms_out) {
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  hipEvent_t e0, e1;
+  OSD_HIP(hipEventCreate(&e0));
+  OSD_HIP(hipEventCreate(&e1));
+  auto run = [&]() {
+    switch (mode) {
+      case 0: hipLaunchKernelGGL((k_mfma_rate<0>), grid, 256, 65536, h->stream, src, dst, nk); break;
+      case 1: hipLaunchKernelGGL((k_mfma_rate<1>), grid, 256, 65536, h->stream, src, dst, nk); break;
+      case 2: hipLaunchKernelGGL((k_mfma_rate<2>), grid, 256, 65536, h->stream, src, dst, nk); break;
+      default: hipLaunchKernelGGL((k_mfma_rate<3>), grid, 256, 65536, h->stream, src, dst, nk); break;
+    }
+  };
+  static bool attr = false;
+  if (!attr) {
+    OSD_HIP(hipFuncSetAttribute((const void*)k_mfma_rate<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    OSD_HIP(hipFuncSetAttribute((const void*)k_mfma_rate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    OSD_HIP(hipFuncSetAttribute((const void*)k_mfma_rate<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    OSD_HIP(hipFuncSetAttribute((const void*)k_mfma_rate<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    attr = true;
+  }
+  run();
+  OSD_HIP(hipEventRecord(e0, h->stream));
+  for (int i = 0; i < 5; ++i) run();
+  OSD_HIP(hipEventRecord(e1, h->stream));
+  OSD_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  OSD_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / 5;
+  OSD_HIP(hipEventDestroy(e0));
+  OSD_HIP(hipEventDestroy(e1));
+  return OSD_OK;
+}

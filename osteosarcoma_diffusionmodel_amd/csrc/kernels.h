@@ -13,7 +13,7 @@ hipError_t launch_linear(hipStream_t s, const GemmArgs& g, bool a_kc, bool b_kc,
                          float* out, int ldo, bool silu, bool accumulate);
 
 // k_fused.hip ----------------------------------------------------------------------
-hipError_t launch_input(hipStream_t s, const GemmArgs& g, const EpiInput::Args& a);
+hipError_t launch_input(hipStream_t s, const GemmArgs& g, const EpiInput::Args& a, bool a_zero_padded);
 hipError_t launch_posterior(hipStream_t s, const GemmArgs& g, const EpiPosterior::Args& a);
 hipError_t launch_mse(hipStream_t s, const GemmArgs& g, const EpiMse::Args& a);
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <vector>
 #include "gemm.h"
+#include "gemm_glds.h"
 
 namespace osd {
 
@@ -59,9 +60,38 @@ hipError_t launch_gemm_v(hipStream_t s, const GemmArgs& g, const typename Epi::A
   return hipGetLastError();
 }
 
+// Preconditions of the direct-to-LDS forward kernel (gemm_glds.h).  a_zero_padded: the caller
+// guarantees A is readable and zero for k in [K, roundup(K, BK)).
+inline bool glds_ok(const GemmArgs& g, bool a_zero_padded) {
+  if (!ptr_al16(g.A) || !ptr_al16(g.B0) || g.lda % 4 || g.ldb0 % 4 || g.K < 4 || g.K % 4) return false;
+  if (g.K % BK && !a_zero_padded) return false;
+  if (g.K0 < g.K && (g.K0 % BK || (g.K - g.K0) % 4 || g.K - g.K0 < 4 || !ptr_al16(g.B1) || g.ldb1 % 4)) return false;
+  return true;
+}
+
+template <class T, class Epi>
+struct GldsRegistrar {
+  GldsRegistrar() { kernel_registry().push_back({reinterpret_cast<const void*>(gemm_glds_kernel<T, Epi>), GldsTile<T>::LDS_BYTES}); }
+  static GldsRegistrar instance;
+};
+template <class T, class Epi>
+GldsRegistrar<T, Epi> GldsRegistrar<T, Epi>::instance;
+
+template <class T, class Epi>
+hipError_t launch_gemm_glds(hipStream_t s, const GemmArgs& g, const typename Epi::Args& ea) {
+  (void)&GldsRegistrar<T, Epi>::instance;
+  const int grid = gemm_grid(g.F, g.P, T::BF, T::BP);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, Epi>), dim3(grid), dim3(NTHREADS), GldsTile<T>::LDS_BYTES, s, g, ea);
+  return hipGetLastError();
+}
+
+// a_zero_padded only matters for the forward (KC x KC) layout.
 template <class T, bool AKC, bool BKC, class Epi>
-hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, const typename Epi::Args& ea) {
+hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, const typename Epi::Args& ea, bool a_zero_padded = false) {
   if (g.F <= 0 || g.P <= 0) return hipSuccess;
+  if constexpr (AKC && BKC) {
+    if (glds_ok(g, a_zero_padded) && Epi::fast_ok(ea, g.F)) return launch_gemm_glds<T, Epi>(s, g, ea);
+  }
   if (gemm_fast_ok(g, AKC, BKC) && Epi::fast_ok(ea, g.F)) return launch_gemm_v<T, AKC, BKC, Epi, true>(s, g, ea);
   return launch_gemm_v<T, AKC, BKC, Epi, false>(s, g, ea);
 }

@@ -124,13 +124,8 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   }
 
   // ---- forward (models/diffusion.py:361-377) ----
-  // the t_emb table follows the current time_proj weights
-  {
-    GemmArgs g{};
-    g.A = h->params[pm.tp_w]; g.lda = a.time_dim; g.B0 = h->d_time_emb; g.ldb0 = a.time_dim; g.K0 = a.time_dim;
-    g.F = a.H0; g.P = a.T; g.K = a.time_dim;
-    OSD_HIP(launch_linear(s, g, true, true, h->params[pm.tp_b], h->d_temb, a.H0, false, false));
-  }
+  // the t_emb table and the padded input_proj.weight follow the current parameters
+  OSD_TRY(refresh_derived(h, s));
   const int* t_idx = t_index;
   if (!t_idx) { OSD_HIP(launch_randint(s, w.t_idx, n, a.T, seed, roff)); t_idx = w.t_idx; }
   OSD_HIP(launch_q_sample(s, x0, t_idx, h->d_sqrt_ac, h->d_sqrt_1m, noise, n, D, seed, roff, w.x_t, w.noise));
