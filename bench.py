@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-rows", type=int, default=0, help="rows for the per-kernel event timing (default: chunk)")
+    ap.add_argument("--profile-only", action="store_true", help="run only the per-kernel roofline leg (for rocprofv3 --stats)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,6 +111,9 @@ def main():
         out, mask = model.sample(cond, n, seed=1234 + i, row_offset=offset, return_mutation_mask=True)
         return out, mask
 
+    if args.profile_only:
+        args.steps, args.warmup, n = 0, 0, min(n, 1024)
+        cond = cond[:n].contiguous()
     for i in range(args.warmup):
         step(i)
 
@@ -124,12 +128,13 @@ def main():
     for i in range(args.steps):
         out, mask = step(args.warmup + i)
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = max(time.perf_counter() - t0, 1e-9)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert torch.isfinite(out).all().item()
+    if args.steps:
+        assert torch.isfinite(out).all().item()
     total_patients = n * world * args.steps
     value = total_patients / elapsed
 
@@ -137,7 +142,13 @@ def main():
     if rank == 0:
         # per-kernel durations with HIP events on the launch stream, same process, same shapes
         eng = model._engine()
-        rows = args.profile_rows or min(n, model.sample_chunk_rows or 32768)
+        # rows per launch of the timed region: equal chunks of at most chunk_rows, whole 128-row tiles
+        chunk_cap = model.sample_chunk_rows or 65536
+        n_chunks = -(-args.patients // chunk_cap)
+        chunk_rows = min(args.patients, (-(-args.patients // n_chunks) + 127) // 128 * 128)
+        rows = args.profile_rows or chunk_rows
+        if rows > cond.shape[0]:
+            cond = scenario_conditions(rows, offset).to(dev)
         ms = (C.c_float * 64)()
         fl = (C.c_double * 64)()
         ne = C.c_int()
@@ -153,9 +164,16 @@ def main():
         dom_fl = float(np.mean([fl[i] for i in wide]))
         achieved = dom_fl / (dom_ms * 1e-3) / 1e12
         step_ms = float(sum(ms[i] for i in range(ne)))
-        roof = {"bound": "mfma", "kernel": "gemm_kernel<Tile128x128, EpiGnSilu<64>> (Linear+GroupNorm+SiLU, 512-wide layers)",
+        # HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes (profiles/r01_pmc.md:
+        # 2 x FETCH_SIZE + WRITE_SIZE at 32 768 rows), scaled to this launch's rows
+        traffic = None
+        tj = ROOT / "profiles" / "r01_traffic.json"
+        if tj.exists():
+            t = json.loads(tj.read_text())
+            traffic = round(t["traffic_bytes_per_launch"]["GnSilu<64> glds"] * rows / t["rows_per_launch"])
+        roof = {"bound": "mfma", "kernel": "gemm_glds_kernel<Tile<128,128,64,64>, EpiGnSilu<64>> (Linear+GroupNorm+SiLU, 512-wide layers)",
                 "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "avg_launch_ms": round(dom_ms, 4), "rows_per_launch": rows,
                 "whole_step": {"ms": round(step_ms, 3),
                                "tflops": round(rows * FLOP_PER_PATIENT_STEP / (step_ms * 1e-3) / 1e12, 2)},
@@ -166,13 +184,13 @@ def main():
     if rank == 0:
         line = {
             "metric": "synthetic patients/sec (full T-step reverse sample)", "value": round(value, 2), "unit": "patients/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 2),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / max(args.steps, 1), 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "reverse sampling of conditional patients, T=1000, D=2000 (50 mut + 1900 expr + 50 pathway), "
                                    "hidden [256,512,256], 3 scenario conditions, hipGraph-captured p_sample step",
                        "patients_per_gpu": n, "global_patients_per_step": n * world, "T": 1000,
                        "parallelism": f"patients sharded over {world} GPU(s), no collective",
-                       "chunk_rows": model.sample_chunk_rows or 32768, "streams": model.sample_streams or 2,
+                       "chunk_rows": model.sample_chunk_rows or 65536, "streams": model.sample_streams or 2,
                        "graph": model.use_graph},
             "achieved_tflops_end_to_end": round(value * 1000 * FLOP_PER_PATIENT_STEP / 1e12 / world, 2),
             "roofline": roof, "cpu_baseline": cpu,

@@ -1,0 +1,100 @@
+"""CPU, world_size 2 over gloo: the data-parallel host logic (osteosarcoma_diffusionmodel_amd/parallel.py)
+that bench.py and Trainer use on N GPUs -- patient sharding with no collective, and the bucketed
+gradient all-reduce in backward order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from osteosarcoma_diffusionmodel_amd import _lib as L
+from osteosarcoma_diffusionmodel_amd.parallel import allreduce_buckets, bucket_slices, shard_rows
+
+
+def test_shard_rows_partition():
+    for n in (0, 1, 7, 100000, 3000000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_rows(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0
+            assert sum(c for _, c in spans) == n
+            for (o0, c0), (o1, _) in zip(spans, spans[1:]):
+                assert o0 + c0 == o1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def _cfg():
+    import ctypes as C
+    cfg = L.OsdConfig()
+    cfg.mutation_dim, cfg.expression_dim, cfg.pathway_dim, cfg.condition_dim = 50, 1900, 50, 3
+    cfg.time_dim, cfg.n_hidden = 128, 3
+    for i, v in enumerate((256, 512, 256)):
+        cfg.hidden_dims[i] = v
+    cfg.num_steps, cfg.dropout_p = 1000, 0.2
+    return cfg
+
+
+def _buckets():
+    import ctypes as C
+    cfg = _cfg()
+    lib = L.lib()
+    nb = lib.osd_grad_buckets(C.byref(cfg), None, None, 0)
+    first, last = (C.c_int32 * nb)(), (C.c_int32 * nb)()
+    lib.osd_grad_buckets(C.byref(cfg), first, last, nb)
+    numel = [lib.osd_param_numel(C.byref(cfg), i) for i in range(lib.osd_num_params(C.byref(cfg)))]
+    return [(int(first[i]), int(last[i])) for i in range(nb)], numel
+
+
+def test_grad_buckets_cover_every_parameter_once_in_backward_order():
+    buckets, numel = _buckets()
+    assert buckets[0] == (50, 51)                       # output_proj is final first
+    assert buckets[-1] == (0, 9)                        # embeddings + input/cond/time proj last
+    covered = sorted(i for f, l in buckets for i in range(f, l + 1))
+    assert covered == list(range(52))
+    offsets = np.concatenate([[0], np.cumsum(numel)])
+    sl = bucket_slices(offsets, buckets)
+    assert sum(e - s for s, e in sl) == 2663952
+    assert all(s0 >= e1 for (s0, _), (_, e1) in zip(sl, sl[1:]))      # descending, non-overlapping
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        buckets, numel = _buckets()
+        offsets = np.concatenate([[0], np.cumsum(numel)])
+        sl = bucket_slices(offsets, buckets)
+        g = torch.Generator().manual_seed(100 + rank)
+        local = torch.randn(int(offsets[-1]), generator=g)          # this rank's gradient
+        flat = local / world                                          # the loss_scale = 1/world fold
+        allreduce_buckets(flat, sl)                                   # CPU path: no streams / events
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        mean = torch.stack(gathered).mean(0)
+        ok = torch.allclose(flat, mean, rtol=1e-6, atol=1e-7)
+        # sampling shards: offsets are disjoint and ordered, no communication needed
+        off, cnt = shard_rows(100001, rank, world)
+        spans = [None] * world
+        dist.all_gather_object(spans, (off, cnt))
+        ok = ok and sum(c for _, c in spans) == 100001 and spans[0][0] == 0
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_is_the_mean_gloo_world2():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
