@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <new>
 #include "handle.h"
@@ -24,6 +25,14 @@ void set_error(const char* fmt, ...) {
 std::vector<KernelReg>& kernel_registry() {
   static std::vector<KernelReg> r;
   return r;
+}
+int stagger_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("OSD_STAGGER");
+    mode = e ? atoi(e) : 1;
+  }
+  return mode;
 }
 hipError_t prepare_kernels() {
   for (const KernelReg& k : kernel_registry()) {

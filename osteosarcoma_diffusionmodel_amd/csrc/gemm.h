@@ -36,6 +36,7 @@ struct GemmArgs {
   const float* B1; int ldb1;   // second K panel of a KC B operand (k >= K0); unused when K0 >= K
   int K0;
   int F, P, K;
+  int stagger;                 // gemm_glds_kernel: start delay (units of 64 cycles) of the second co-resident workgroup
 };
 
 template <int BF_, int BP_, int WF_, int WP_>

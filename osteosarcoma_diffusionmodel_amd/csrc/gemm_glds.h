@@ -69,6 +69,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
   if (pt >= npt) return;
   const int f0 = ft * T::BF, p0 = pt * T::BP;
 
+  // Two workgroups share a CU (one wave of each per SIMD) and, launched together, run in lock
+  // step: both are in their VALU-only epilogue at the same time and the matrix pipe idles.  The
+  // workgroup that landed in hardware wave slot 1 of the first round therefore starts half a
+  // tile late; later rounds inherit the phase shift because slots then free up alternately.
+  // (Speed only: HW_REG_HW_ID wave-slot parity, measured placement b / b+256 per CU.)
+  if (g.stagger > 0 && b < 512 && (__builtin_amdgcn_s_getreg(0xF804) & 1u)) {
+    for (int i = 0; i < g.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
+  }
+
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,23 +111,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
     b_row[j] = rg < g.P ? rg : g.P - 1;
     b_k4[j] = 4 * ((lane & 7) ^ ((row >> 1) & 7));
   }
-  auto stage = [&](int k0, float* As, float* Bs) {
-    const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr(As) + (unsigned)wave * 1024u);
-    const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(Bs) + (unsigned)wave * 1024u);
-#pragma unroll
-    for (int j = 0; j < G::NA; ++j) glds16(g.A + (size_t)(a_off[j] + k0), la + (unsigned)j * 4096u);
+  // ---- DMA of one tile, split into single wave-instructions so that each can be issued in the
+  // shadow of the MFMAs of the tile being computed (one LDS-DMA costs the wave ~60 issue cycles;
+  // eight of them in a row leave the matrix pipe idle, one between two groups of MFMAs is free).
+  struct StageCtx { unsigned la, lb; const float* bbase; int bld, bk, bkend, ak; };
+  auto stage_begin = [&](int k0, float* As, float* Bs) {
+    StageCtx c;
+    c.la = __builtin_amdgcn_readfirstlane(lds_addr(As) + (unsigned)wave * 1024u);
+    c.lb = __builtin_amdgcn_readfirstlane(lds_addr(Bs) + (unsigned)wave * 1024u);
     const bool first = k0 < g.K0;          // uniform: K0 is a multiple of BK (or >= K)
-    const float* base = first ? g.B0 : g.B1;
-    const int ld = first ? g.ldb0 : g.ldb1;
-    const int kb = first ? k0 : k0 - g.K0;
-    const int kend = first ? (g.K0 < g.K ? g.K0 : g.K) : g.K - g.K0;
-#pragma unroll
-    for (int j = 0; j < G::NB; ++j) {
-      int k = kb + b_k4[j];
-      k = k < kend - 4 ? k : kend - 4;
-      glds16(base + (size_t)b_row[j] * ld + k, lb + (unsigned)j * 4096u);
+    c.bbase = first ? g.B0 : g.B1;
+    c.bld = first ? g.ldb0 : g.ldb1;
+    c.bk = first ? k0 : k0 - g.K0;
+    c.bkend = first ? (g.K0 < g.K ? g.K0 : g.K) : g.K - g.K0;
+    c.ak = k0;
+    return c;
+  };
+  // piece j in [0, NA + NB): A pieces first
+  auto stage_piece = [&](const StageCtx& c, int j) {
+    if (j < G::NA) {
+      glds16(g.A + (size_t)(a_off[j] + c.ak), __builtin_amdgcn_readfirstlane(c.la + (unsigned)j * 4096u));
+    } else {
+      const int jb = j - G::NA;
+      int k = c.bk + b_k4[jb];
+      k = k < c.bkend - 4 ? k : c.bkend - 4;
+      glds16(c.bbase + (size_t)b_row[jb] * c.bld + k, __builtin_amdgcn_readfirstlane(c.lb + (unsigned)jb * 4096u));
     }
   };
+  constexpr int NPIECE = G::NA + G::NB;
 
   // ---- fragment read offsets: row R, 16-byte chunk (2i+h) ^ ((R>>1)&7) ----
   int a_rd[T::NFB], a_sw[T::NFB], b_rd[T::NPB], b_sw[T::NPB];
@@ -127,7 +147,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
 #pragma unroll
   for (int pb = 0; pb < T::NPB; ++pb) { const int R = wp + 32 * pb + l31; b_rd[pb] = R * BK; b_sw[pb] = h ^ ((R >> 1) & 7); }
 
-  auto compute = [&](const float* As, const float* Bs, int i) {
+  // quarter i of a staged tile; DO_STAGE: also issue DMA pieces [p0, p0 + 2*...) one per k-pair
+  auto compute = [&](const float* As, const float* Bs, int i, const StageCtx& sc, bool do_stage) {
     float a[T::NFB][4], bb[T::NPB][4];
 #pragma unroll
     for (int fb = 0; fb < T::NFB; ++fb) {
@@ -140,27 +161,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
       bb[pb][0] = t.x; bb[pb][1] = t.y; bb[pb][2] = t.z; bb[pb][3] = t.w;
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < 4; ++e) {
 #pragma unroll
       for (int fb = 0; fb < T::NFB; ++fb)
 #pragma unroll
         for (int pb = 0; pb < T::NPB; ++pb)
           acc[fb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fb][e], bb[pb][e], acc[fb][pb], 0, 0, 0);
+      // one DMA piece behind each of the first pieces-per-quarter k-pairs of this quarter
+      constexpr int PPQ = (NPIECE + 3) / 4;
+      if (do_stage && e < PPQ && i * PPQ + e < NPIECE) {
+        __builtin_amdgcn_sched_barrier(0);
+        stage_piece(sc, i * PPQ + e);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   };
 
   const int nk = (g.K + BK - 1) / BK;
-  stage(0, As0, Bs0);
+  {
+    const StageCtx c0 = stage_begin(0, As0, Bs0);
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) stage_piece(c0, j);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the asm DMAs are invisible to hipcc's counters
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     float* Ac = (kt & 1) ? As1 : As0;
     float* Bc = (kt & 1) ? Bs1 : Bs0;
-    if (kt + 1 < nk) stage((kt + 1) * BK, (kt & 1) ? As0 : As1, (kt & 1) ? Bs0 : Bs1);
-    compute(Ac, Bc, 0);
-    compute(Ac, Bc, 1);
-    compute(Ac, Bc, 2);
-    compute(Ac, Bc, 3);
-    // the DMA of tile kt+1 had the whole MFMA block to land; publish it
+    const bool more = kt + 1 < nk;
+    const StageCtx sc = stage_begin(more ? (kt + 1) * BK : 0, (kt & 1) ? As0 : As1, (kt & 1) ? Bs0 : Bs1);
+    compute(Ac, Bc, 0, sc, more);
+    compute(Ac, Bc, 1, sc, more);
+    compute(Ac, Bc, 2, sc, more);
+    compute(Ac, Bc, 3, sc, more);
+    // the DMA of tile kt+1 had the MFMA block to land; publish it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }

@@ -5,7 +5,9 @@
 
 namespace osd {
 
-template <int MODE>
+// MODE 0..4: loop variants; STORE 0: one float per thread, 1: the epilogue's [patient][feature] float4-per-quad
+// pattern (each wave-instruction touches 32 rows), 2: the same bytes as whole 512-byte rows per half wave
+template <int MODE, int STORE = 0>
 __global__ __launch_bounds__(256, 2) void k_mfma_rate(const float* src, float* dst, int nk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -23,10 +25,23 @@ __global__ __launch_bounds__(256, 2) void k_mfma_rate(const float* src, float* d
   float ra[2][4], rb[2][4];
   for (int i = 0; i < 2; ++i) for (int e = 0; e < 4; ++e) { ra[i][e] = 0.001f * (lane + e + i); rb[i][e] = 0.002f * (lane - e + i); }
   const float* gbase = src + (size_t)(blockIdx.x % 64) * 4096 + (wave * 64 + lane) * 4;
+  // MODE 4: operand B as in input_proj -- this block's own 128 rows of a [rows][2000] fp32 matrix
+  // (HBM / Infinity-Cache resident), 8 rows x 128 B per wave-instruction; A from a small shared panel
+  const float* xrow[4];
+  for (int j = 0; j < 4; ++j) {
+    const int row = (j * 4 + wave) * 8 + (lane >> 3);
+    xrow[j] = src + 65536 + ((size_t)blockIdx.x * 128 + row) * 2000 + 4 * (lane & 7);
+  }
   for (int kt = 0; kt < nk; ++kt) {
     const float* Ac = (kt & 1) ? As1 : As0;
     const float* Bc = (kt & 1) ? Bs1 : Bs0;
-    if (MODE >= 3) {
+    if (MODE == 4) {
+      const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr((kt & 1) ? As0 : As1) + (unsigned)wave * 1024u);
+      const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr((kt & 1) ? Bs0 : Bs1) + (unsigned)wave * 1024u);
+      const int k0 = (kt % 62) * 32;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { glds16(gbase + j * 1024 + (kt & 7) * 4096, la + j * 4096u); glds16(xrow[j] + k0, lb + j * 4096u); }
+    } else if (MODE >= 3) {
       const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr((kt & 1) ? As0 : As1) + (unsigned)wave * 1024u);
       const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr((kt & 1) ? Bs0 : Bs1) + (unsigned)wave * 1024u);
 #pragma unroll
@@ -54,9 +69,30 @@ __global__ __launch_bounds__(256, 2) void k_mfma_rate(const float* src, float* d
     if (MODE >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (MODE >= 2) __syncthreads();
   }
-  float s = 0.f;
-  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
-  dst[blockIdx.x * 256 + tid] = s;
+  if (STORE == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    dst[blockIdx.x * 256 + tid] = s;
+  } else {
+    // output tile: 128 patients x 128 features of a [rows][512] matrix, this block's rows
+    float* tile = dst + (size_t)blockIdx.x * 128 * 512;
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = make_float4(acc[fb][pb][4 * q], acc[fb][pb][4 * q + 1], acc[fb][pb][4 * q + 2], acc[fb][pb][4 * q + 3]);
+          if (STORE == 1) {
+            const int f = wf + 32 * fb + 8 * q + 4 * h, p = wp + 32 * pb + l31;
+            *reinterpret_cast<float4*>(tile + (size_t)p * 512 + f) = v;
+          } else {
+            const int j = (fb * 2 + pb) * 4 + q;                 // 16 instructions, each 2 rows x 512 B
+            const int p = wave * 32 + j * 2 + h;
+            *reinterpret_cast<float4*>(tile + (size_t)p * 512 + 4 * l31) = v;
+          }
+        }
+  }
 }
 
 }  // namespace osd
@@ -73,7 +109,10 @@ extern "C" int osd_dbg_mfma_rate(osd_handle* h, int mode, int nk, int grid, cons
       case 0: hipLaunchKernelGGL((k_mfma_rate<0>), grid, 256, 65536, h->stream, src, dst, nk); break;
       case 1: hipLaunchKernelGGL((k_mfma_rate<1>), grid, 256, 65536, h->stream, src, dst, nk); break;
       case 2: hipLaunchKernelGGL((k_mfma_rate<2>), grid, 256, 65536, h->stream, src, dst, nk); break;
-      default: hipLaunchKernelGGL((k_mfma_rate<3>), grid, 256, 65536, h->stream, src, dst, nk); break;
+      case 3: hipLaunchKernelGGL((k_mfma_rate<3>), grid, 256, 65536, h->stream, src, dst, nk); break;
+      case 5: hipLaunchKernelGGL((k_mfma_rate<3, 1>), grid, 256, 65536, h->stream, src, dst, nk); break;
+      case 6: hipLaunchKernelGGL((k_mfma_rate<3, 2>), grid, 256, 65536, h->stream, src, dst, nk); break;
+      default: hipLaunchKernelGGL((k_mfma_rate<4>), grid, 256, 65536, h->stream, src, dst, nk); break;
     }
   };
   static bool attr = false;
@@ -82,6 +121,9 @@ extern "C" int osd_dbg_mfma_rate(osd_handle* h, int mode, int nk, int grid, cons
     OSD_HIP(hipFuncSetAttribute((const void*)k_mfma_rate<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     OSD_HIP(hipFuncSetAttribute((const void*)k_mfma_rate<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     OSD_HIP(hipFuncSetAttribute((const void*)k_mfma_rate<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    OSD_HIP(hipFuncSetAttribute((const void*)k_mfma_rate<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    OSD_HIP(hipFuncSetAttribute((const void*)k_mfma_rate<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    OSD_HIP(hipFuncSetAttribute((const void*)k_mfma_rate<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     attr = true;
   }
   run();
@@ -94,5 +136,30 @@ extern "C" int osd_dbg_mfma_rate(osd_handle* h, int mode, int nk, int grid, cons
   *ms_out = ms / 5;
   OSD_HIP(hipEventDestroy(e0));
   OSD_HIP(hipEventDestroy(e1));
+  return OSD_OK;
+}
+
+// census: which hardware slots do the workgroups of a 2-per-CU launch land on?
+namespace osd {
+__global__ __launch_bounds__(256, 2) void k_census(unsigned* out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  smem[threadIdx.x] = 1.f;       // touch LDS so the dynamic size limits residency to 2 per CU
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg(0xF804);      // HW_REG_HW_ID, 32 bits
+    const unsigned xcc = __builtin_amdgcn_s_getreg(0xF814);     // HW_REG_XCC_ID
+    out[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2] = hw;
+    out[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 1] = xcc;
+  }
+  // stay resident long enough for the whole grid to be placed
+  for (int i = 0; i < 200; ++i) __builtin_amdgcn_s_sleep(127);
+}
+}  // namespace osd
+extern "C" int osd_dbg_census(osd_handle* h, int grid, unsigned* out) {
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  OSD_HIP(hipFuncSetAttribute((const void*)osd::k_census, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  hipLaunchKernelGGL(osd::k_census, grid, 256, 65536, h->stream, out);
+  OSD_HIP(hipGetLastError());
+  OSD_HIP(hipStreamSynchronize(h->stream));
   return OSD_OK;
 }

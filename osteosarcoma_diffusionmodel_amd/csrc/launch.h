@@ -77,10 +77,16 @@ struct GldsRegistrar {
 template <class T, class Epi>
 GldsRegistrar<T, Epi> GldsRegistrar<T, Epi>::instance;
 
+int stagger_mode();   // OSD_STAGGER env: 0 off, 1 (default) on for launches of >= 2 rounds, 2 always
+
 template <class T, class Epi>
-hipError_t launch_gemm_glds(hipStream_t s, const GemmArgs& g, const typename Epi::Args& ea) {
+hipError_t launch_gemm_glds(hipStream_t s, const GemmArgs& g0, const typename Epi::Args& ea) {
   (void)&GldsRegistrar<T, Epi>::instance;
+  GemmArgs g = g0;
   const int grid = gemm_grid(g.F, g.P, T::BF, T::BP);
+  const int mode = stagger_mode();
+  g.stagger = 0;
+  if (mode == 2 || (mode == 1 && grid >= 1024)) g.stagger = ((g.K + BK - 1) / BK) * 64;   // ~ half a tile: nk * 4096 cycles
   hipLaunchKernelGGL((gemm_glds_kernel<T, Epi>), dim3(grid), dim3(NTHREADS), GldsTile<T>::LDS_BYTES, s, g, ea);
   return hipGetLastError();
 }

@@ -15,12 +15,12 @@ lib = L.lib()
 fn = lib.osd_dbg_mfma_rate
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
-src = torch.randn(64 * 4096 + 65536, device="cuda")
-dst = torch.zeros(4096 * 256, device="cuda")
-names = {0: "MFMA only", 1: "+LDS fragment reads", 2: "+barrier/step", 3: "+glds DMA"}
-for grid in (256, 512, 1024):
-    for mode in range(4):
-        for nk in (8, 64):
+src = torch.randn(65536 + 1024 * 128 * 2000 + 4096, device="cuda")
+dst = torch.zeros(1024 * 128 * 512, device="cuda")
+names = {0: "MFMA only", 1: "+LDS fragment reads", 2: "+barrier/step", 3: "+glds DMA (L2-hot)", 4: "+glds DMA (x rows from HBM)", 5: "+DMA +quad stores [p][f]", 6: "+DMA +row stores"}
+for grid in (512, 1024):
+    for mode in (2, 3, 5, 6):
+        for nk in (8, 16):
             ms = C.c_float()
             L.check(fn(rh.h, mode, nk, grid, L.ptr(src), L.ptr(dst), C.byref(ms)))
             flops = grid * 4 * 64 * nk * 4096.0       # waves * MFMAs/step * steps * flop/MFMA
