@@ -24,8 +24,9 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 // ---- bias (+ optional SiLU, + optional accumulate into out) -----------------------
 template <bool SILU, bool ACCUM>
 struct EpiBias {
-  struct Args { const float* bias; float* out; int ldo; };
-  static bool fast_ok(const Args& a, int F) { return F % 4 == 0 && al16(a.bias) && al16(a.out) && a.ldo % 4 == 0; }
+  struct Args { const float* bias; float* out; int ldo; long long slice_stride; };
+  static bool fast_ok(const Args& a, int F) { return F % 4 == 0 && al16(a.bias) && al16(a.out) && a.ldo % 4 == 0 && a.slice_stride % 4 == 0; }
+  static __device__ __forceinline__ void slice(Args& a, int y) { a.out += (long long)y * a.slice_stride; }
   template <int NFB, int NPB, bool FAST>
   static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, int fw, int pw, int lane, int F, int P) {
     const int l31 = lane & 31, h = lane >> 5;
@@ -45,6 +46,7 @@ struct EpiBias {
 
 // ---- input_proj: h = ((x W^T + b) + t_emb[t]) + c_proj   (models/diffusion.py:229-232) ----
 struct EpiInput {
+  template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias;
     const float* temb; int ldt;   // [T][F] time_proj(TimeEmbedding(t/T))
@@ -94,6 +96,7 @@ struct EpiInput {
 // (mean, rstd) for backward.
 template <int GW, bool DROP>
 struct EpiGnSilu {
+  template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias; const float* gamma; const float* beta;
     float* out; int ldo;
@@ -195,6 +198,7 @@ struct EpiGnSilu {
 // (osd_set_schedule), which replaces three IEEE divides per element by two FMAs; the result
 // differs from the reference's op order by a few ulp of the same intermediate magnitudes.
 struct EpiPosterior {
+  template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias;
     const float* xin; int ldx;
@@ -249,6 +253,7 @@ struct EpiPosterior {
 // ---- output_proj fused with the MSE loss (models/diffusion.py:373-377) and its gradient ----
 // d = (acc + bias) - noise;  loss += sum d^2 * inv_count;  dout = d * gscale
 struct EpiMse {
+  template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias; const float* noise; int ldn;
     float* dout; int ldd;         // may be null (validation: loss only)

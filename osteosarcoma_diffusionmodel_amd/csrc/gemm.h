@@ -36,6 +36,7 @@ struct GemmArgs {
   const float* B1; int ldb1;   // second K panel of a KC B operand (k >= K0); unused when K0 >= K
   int K0;
   int F, P, K;
+  int kchunk;                  // gemm_kernel split-K: blockIdx.y reduces k in [y*kchunk, (y+1)*kchunk); 0 = no split
   int stagger;                 // gemm_glds_kernel: start delay (units of 64 cycles) of the second co-resident workgroup
 };
 
@@ -187,6 +188,16 @@ struct StageNK {
 // Epi::apply<NFB,NPB,FAST>(acc, args, f_wave, p_wave, lane, F, P) consumes the wave's accumulators.
 template <class T, bool AKC, bool BKC, class Epi, bool FAST>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g, typename Epi::Args ea) {
+  // split-K (wgrad: the reduction runs over the batch): slice y owns k in [y*kchunk, (y+1)*kchunk) and
+  // writes its partial tile to its own slab (Epi::slice moves the output pointer); single K panel only.
+  if (g.kchunk > 0) {
+    const int kb = blockIdx.y * g.kchunk;
+    g.A += AKC ? (size_t)kb : (size_t)kb * g.lda;
+    g.B0 += BKC ? (size_t)kb : (size_t)kb * g.ldb0;
+    g.K = (g.K - kb < g.kchunk) ? g.K - kb : g.kchunk;
+    g.K0 = g.K;
+    Epi::slice(ea, blockIdx.y);
+  }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As0 = smem;
   float* As1 = smem + T::A_ELEMS;

@@ -5,10 +5,20 @@
 namespace osd {
 
 template <bool AKC, bool BKC, bool SILU, bool ACC>
-static hipError_t go(hipStream_t s, const GemmArgs& g, const float* bias, float* out, int ldo) {
-  typename EpiBias<SILU, ACC>::Args ea{bias, out, ldo};
+static hipError_t go(hipStream_t s, const GemmArgs& g, const float* bias, float* out, int ldo, long long slice_stride = 0) {
+  typename EpiBias<SILU, ACC>::Args ea{bias, out, ldo, slice_stride};
   if (use_big_tile(g.F, g.P)) return launch_gemm<TileBig, AKC, BKC, EpiBias<SILU, ACC>>(s, g, ea);
+  const long small_tiles = (long)((g.F + 63) / 64) * ((g.P + 127) / 128) * (g.kchunk > 0 ? (g.K + g.kchunk - 1) / g.kchunk : 1);
+  if constexpr (!(AKC && BKC)) {
+    // backward layouts: 64x64 tiles when the 64x128 grid would leave most CUs idle
+    if (small_tiles < 512) return launch_gemm<Tile64, AKC, BKC, EpiBias<SILU, ACC>>(s, g, ea);
+  }
   return launch_gemm<TileSmall, AKC, BKC, EpiBias<SILU, ACC>>(s, g, ea);
+}
+
+// wgrad with the batch reduction split over blockIdx.y: slice y writes slab + y*slice_stride
+hipError_t launch_wgrad_splitk(hipStream_t s, const GemmArgs& g, float* slabs, int ldo, long long slice_stride) {
+  return go<false, false, false, false>(s, g, nullptr, slabs, ldo, slice_stride);
 }
 
 hipError_t launch_linear(hipStream_t s, const GemmArgs& g, bool a_kc, bool b_kc, const float* bias,

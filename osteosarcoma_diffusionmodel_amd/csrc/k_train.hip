@@ -97,6 +97,7 @@ hipError_t launch_scatter_rows(hipStream_t s, const float* g, const int* t, int6
 //   g_z = rstd * (g_zhat - mean_g(g_zhat) - zhat*mean_g(g_zhat*zhat))
 template <int GW, int NJ>
 __global__ __launch_bounds__(256) void k_gn_silu_bwd(GnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];      // [3][4 waves][C]
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -160,32 +161,58 @@ __global__ __launch_bounds__(256) void k_gn_silu_bwd(GnBwdArgs a) {
       if (in) st4g(a.gz + r * C, c, C, make_float4(gz[0], gz[1], gz[2], gz[3]));
     }
   }
+  // column sums: waves of the block through LDS, then one partial row per block (summed by
+  // k_partial_reduce in a fixed order: deterministic, no atomics)
+  const int w = threadIdx.x >> 6;
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int c = 4 * lane + 256 * j + e;
       if (c < C) {
-        atomicAdd(a.dgamma + c, acc_g[j][e]);
-        atomicAdd(a.dbeta + c, acc_b[j][e]);
-        atomicAdd(a.dbias + c, acc_z[j][e]);
+        red[(0 * 4 + w) * C + c] = acc_g[j][e];
+        red[(1 * 4 + w) * C + c] = acc_b[j][e];
+        red[(2 * 4 + w) * C + c] = acc_z[j][e];
       }
     }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
+    const int q = i / C, c = i - q * C;
+    const float v = (red[(q * 4 + 0) * C + c] + red[(q * 4 + 1) * C + c]) + (red[(q * 4 + 2) * C + c] + red[(q * 4 + 3) * C + c]);
+    a.partials[(size_t)blockIdx.x * 3 * C + i] = v;
+  }
+}
+
+// out_q[c] = sum_b partials[b][q][c], q = 0..2 -> (dgamma, dbeta, dbias)
+__global__ void k_partial_reduce(const float* partials, int nb, int C, float* o0, float* o1, float* o2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * C) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += partials[(size_t)b * 3 * C + i];
+  const int q = i / C, c = i - q * C;
+  (q == 0 ? o0 : q == 1 ? o1 : o2)[c] = s;
+}
+
+int gn_bwd_blocks(int64_t rows) {
+  int blocks = (int)((rows + 15) / 16);      // ~4 rows per wave
+  if (blocks > GN_BWD_MAX_BLOCKS) blocks = GN_BWD_MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  return blocks;
 }
 
 template <int GW>
 static hipError_t gn_bwd_go(hipStream_t s, const GnBwdArgs& a) {
   const int nj = (a.C + 255) / 256;
-  int blocks = (int)((a.rows + 15) / 16);      // ~4 rows per wave
-  if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
+  const int blocks = gn_bwd_blocks(a.rows);
+  const size_t lds = (size_t)3 * 4 * a.C * sizeof(float);
   switch (nj) {
-    case 1: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 1>), blocks, 256, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 2>), blocks, 256, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 3>), blocks, 256, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 4>), blocks, 256, 0, s, a); break;
+    case 1: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 1>), blocks, 256, lds, s, a); break;
+    case 2: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 2>), blocks, 256, lds, s, a); break;
+    case 3: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 3>), blocks, 256, lds, s, a); break;
+    case 4: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 4>), blocks, 256, lds, s, a); break;
     default: return hipErrorInvalidValue;
   }
+  hipLaunchKernelGGL(k_partial_reduce, (3 * a.C + 255) / 256, 256, 0, s, a.partials, blocks, a.C, a.dgamma, a.dbeta, a.dbias);
   return hipGetLastError();
 }
 hipError_t launch_gn_silu_bwd(hipStream_t s, int gw, const GnBwdArgs& a) {
@@ -199,6 +226,51 @@ hipError_t launch_gn_silu_bwd(hipStream_t s, int gw, const GnBwdArgs& a) {
     case 128: return gn_bwd_go<128>(s, a);
     default: return hipErrorInvalidValue;
   }
+}
+
+// ---- split-K wgrad: out[r][c] = sum_s slabs[s][r][c] (fixed order), out has leading dimension ldo ----
+__global__ void k_slab_reduce(const float* slabs, int ns, int rows, int cols, int64_t stride, float* out, int ldo) {
+  const int c4n = cols >> 2;
+  const int64_t total = (int64_t)rows * c4n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / c4n);
+    const int c = 4 * (int)(i - (int64_t)r * c4n);
+    const float* p = slabs + (size_t)r * cols + c;
+    float4 acc = *reinterpret_cast<const float4*>(p);
+    for (int sidx = 1; sidx < ns; ++sidx) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)sidx * stride);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)r * ldo + c) = acc;
+  }
+}
+hipError_t launch_slab_reduce(hipStream_t s, const float* slabs, int ns, int rows, int cols, int64_t stride, float* out, int ldo) {
+  if (rows <= 0 || cols <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_slab_reduce, ew_grid((int64_t)rows * cols / 4), 256, 0, s, slabs, ns, rows, cols, stride, out, ldo);
+  return hipGetLastError();
+}
+
+// ---- wgrad of a Linear with very few inputs (the condition MLP, cond_dim ~ 3):
+// dW[n][k] = sum_m gz[m][n] * x[m][k], one thread per (n,k), rows split over blocks, atomics at the end
+__global__ void k_small_wgrad(const float* x, int kin, const float* gz, int ldg, int nout, int64_t rows, int rows_per_block, float* dw) {
+  const int i = threadIdx.x;
+  if (i >= nout * kin) return;
+  const int n = i / kin, k = i - n * kin;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  float s = 0.f;
+  for (int64_t r = r0; r < r1; ++r) s += gz[r * ldg + n] * x[r * kin + k];
+  atomicAdd(dw + i, s);
+}
+hipError_t launch_small_wgrad(hipStream_t s, const float* x, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw) {
+  if (rows <= 0) return hipSuccess;
+  if (nout * kin > 1024) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(dw, 0, (size_t)nout * kin * 4, s);
+  if (e != hipSuccess) return e;
+  const int rpb = 64;
+  hipLaunchKernelGGL(k_small_wgrad, (unsigned)((rows + rpb - 1) / rpb), 1024, 0, s, x, kin, gz, ldg, nout, rows, rpb, dw);
+  return hipGetLastError();
 }
 
 // ---- clip_grad_norm_ + AdamW over flat buffers -----------------------------------------------

@@ -12,6 +12,8 @@ namespace osd {
 hipError_t launch_linear(hipStream_t s, const GemmArgs& g, bool a_kc, bool b_kc, const float* bias,
                          float* out, int ldo, bool silu, bool accumulate);
 
+hipError_t launch_wgrad_splitk(hipStream_t s, const GemmArgs& g, float* slabs, int ldo, long long slice_stride);
+
 // k_fused.hip ----------------------------------------------------------------------
 hipError_t launch_input(hipStream_t s, const GemmArgs& g, const EpiInput::Args& a, bool a_zero_padded);
 hipError_t launch_posterior(hipStream_t s, const GemmArgs& g, const EpiPosterior::Args& a);

@@ -19,12 +19,16 @@ struct GnBwdArgs {
   const float* stats;    // (mean, rstd)                   [rows][8][2]
   const float* gamma; const float* beta;
   float* gz;             // dL/dz                          [rows][C]
-  float* dgamma; float* dbeta; float* dbias;   // [C], accumulated atomically (zeroed by the caller)
+  float* dgamma; float* dbeta; float* dbias;   // [C], overwritten
+  float* partials;                             // workspace [GN_BWD_MAX_BLOCKS][3][C]
   int64_t rows; int C;
   int drop_mode; const float* mask; float keep_scale; float p_drop;
   uint64_t seed; uint32_t row_offset; uint32_t step; uint32_t tag;
 };
+constexpr int GN_BWD_MAX_BLOCKS = 256;
 hipError_t launch_gn_silu_bwd(hipStream_t s, int gw, const GnBwdArgs& a);
+hipError_t launch_slab_reduce(hipStream_t s, const float* slabs, int ns, int rows, int cols, int64_t stride, float* out, int ldo);
+hipError_t launch_small_wgrad(hipStream_t s, const float* x, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw);
 
 struct AdamArgs {
   float decay;          // 1 - lr*wd

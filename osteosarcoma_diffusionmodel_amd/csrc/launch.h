@@ -9,6 +9,7 @@ namespace osd {
 typedef Tile<128, 128, 64, 64> TileBig;     // 2x2 waves of 64f x 64p; sampling-sized batches
 typedef Tile<64, 128, 64, 32> TileSmall;    // 1x4 waves of 64f x 32p; training-sized batches
 typedef Tile<128, 128, 128, 32> TileWide;   // 1x4 waves of 128f x 32p; GroupNorm groups of 128
+typedef Tile<64, 64, 32, 32> Tile64;        // 2x2 waves of 32f x 32p; backward GEMMs at training batch sizes
 
 inline int gemm_grid(int F, int P, int BF, int BP) {
   const int nft = (F + BF - 1) / BF, npt = (P + BP - 1) / BP;
@@ -56,7 +57,8 @@ hipError_t launch_gemm_v(hipStream_t s, const GemmArgs& g, const typename Epi::A
   (void)&GemmRegistrar<T, AKC, BKC, Epi, FAST>::instance;   // odr-use: forces the registration
   auto kern = gemm_kernel<T, AKC, BKC, Epi, FAST>;
   const int grid = gemm_grid(g.F, g.P, T::BF, T::BP);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), T::LDS_BYTES, s, g, ea);
+  const int slices = g.kchunk > 0 ? (g.K + g.kchunk - 1) / g.kchunk : 1;
+  hipLaunchKernelGGL(kern, dim3(grid, slices), dim3(NTHREADS), T::LDS_BYTES, s, g, ea);
   return hipGetLastError();
 }
 

@@ -19,6 +19,9 @@ struct TrainWs {
   float *g_h0, *g_ce2, *g_ce1, *g_u, *g_temb;
   std::vector<float*> g_out, g_z2, g_mid, g_z1;
   double* normsq;
+  float* partials;   // gn backward column partials
+  float* slabs;      // split-K wgrad partial tiles
+  int64_t slab_floats;
 };
 
 static int64_t carve_train(const Arch& a, float* base, int64_t n, TrainWs* w) {
@@ -38,15 +41,34 @@ static int64_t carve_train(const Arch& a, float* base, int64_t n, TrainWs* w) {
     w->g_out[b] = take(n * c); w->g_z2[b] = take(n * c); w->g_mid[b] = take(n * c); w->g_z1[b] = take(n * c);
   }
   w->normsq = (double*)take(16);
+  int cmax = 0;
+  for (int c : a.block_out) cmax = c > cmax ? c : cmax;
+  w->partials = take((int64_t)GN_BWD_MAX_BLOCKS * 3 * cmax);
+  w->slab_floats = 16 * 1024 * 1024;      // 64 MB of split-K slabs
+  w->slabs = take(w->slab_floats);
   return off;
 }
 
 // out[p][f] = sum_k A(f,k) B(p,k) helpers for the two backward GEMM shapes
-static hipError_t wgrad(hipStream_t s, const float* x, int ldx, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, int lddw) {
-  // dW[n_out][k_in] = sum_m gz[m][n_out] * x[m][k_in]
+// dW[n_out][k_in] = sum_m gz[m][n_out] * x[m][k_in].  The reduction runs over the batch, the output is only
+// n_out x k_in: split the batch over blockIdx.y so that ~1024 workgroups exist, each writing its partial
+// tile to a slab, then sum the slabs in a fixed order (deterministic; no float atomics).
+static hipError_t wgrad(hipStream_t s, const TrainWs& w, const float* x, int ldx, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, int lddw) {
+  if (kin <= 8 && nout * kin <= 1024 && lddw == kin) return launch_small_wgrad(s, x, kin, gz, ldg, nout, rows, dw);
   GemmArgs g{};
   g.A = x; g.lda = ldx; g.B0 = gz; g.ldb0 = ldg; g.K0 = (int)rows; g.F = kin; g.P = nout; g.K = (int)rows;
-  return launch_linear(s, g, false, false, nullptr, dw, lddw, false, false);
+  const long tiles = (long)((kin + 63) / 64) * ((nout + 63) / 64);
+  int slices = (int)((1024 + tiles - 1) / tiles);
+  const int max_slices = (int)((rows + 127) / 128);
+  if (slices > max_slices) slices = max_slices;
+  const int64_t numel = (int64_t)nout * kin;
+  while (slices > 1 && (int64_t)slices * numel > w.slab_floats) --slices;
+  if (slices <= 1 || kin % 4 || lddw % 4 || (reinterpret_cast<uintptr_t>(dw) & 15)) return launch_linear(s, g, false, false, nullptr, dw, lddw, false, false);
+  g.kchunk = (int)(((rows + slices - 1) / slices + 31) / 32 * 32);
+  const int ns = (int)((rows + g.kchunk - 1) / g.kchunk);
+  hipError_t e = launch_wgrad_splitk(s, g, w.slabs, kin, numel);
+  if (e != hipSuccess) return e;
+  return launch_slab_reduce(s, w.slabs, ns, nout, kin, numel, dw, lddw);
 }
 static hipError_t dgrad(hipStream_t s, const float* w, int ldw, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dx, int lddx, bool accumulate) {
   // dX[m][k_in] (+)= sum_n gz[m][n] * W[n][k_in]
@@ -117,7 +139,6 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
       add(w.g_temb, (int64_t)a.T * a.H0);
       const int small[] = {pm.ce0_b, pm.ce2_b, pm.in_b, pm.cp_b, pm.tp_b, pm.out_b};
       for (int i : small) add(grads[i], pm.numel[i]);
-      for (const LayerDesc& l : a.layers) { add(grads[l.b], l.N); add(grads[l.gamma], l.N); add(grads[l.beta], l.N); }
     }
     if (zl.n > 128) { set_error("too many parameter tensors"); return OSD_EUNSUPPORTED; }
     OSD_HIP(launch_zero_many(s, zl));
@@ -167,7 +188,7 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
     return OSD_OK;
   };
   // output_proj
-  OSD_HIP(wgrad(s, W.f.out[last], Hl, Hl, W.d_out, D, D, n, grads[pm.out_w], Hl));
+  OSD_HIP(wgrad(s, W, W.f.out[last], Hl, Hl, W.d_out, D, D, n, grads[pm.out_w], Hl));
   OSD_HIP(launch_colsum(s, W.d_out, D, n, D, grads[pm.out_b]));
   OSD_TRY(record());
   OSD_HIP(dgrad(s, h->params[pm.out_w], Hl, Hl, W.d_out, D, D, n, W.g_out[last], Hl, false));
@@ -181,26 +202,26 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
     GnBwdArgs ga{};
     ga.g = W.g_out[b]; ga.z = W.f.z2[b]; ga.stats = W.f.st2[b]; ga.gamma = h->params[l2.gamma]; ga.beta = h->params[l2.beta];
     ga.gz = W.g_z2[b]; ga.dgamma = grads[l2.gamma]; ga.dbeta = grads[l2.beta]; ga.dbias = grads[l2.b];
-    ga.rows = n; ga.C = C; ga.drop_mode = 0;
+    ga.rows = n; ga.C = C; ga.drop_mode = 0; ga.partials = W.partials;
     OSD_HIP(launch_gn_silu_bwd(s, l2.gw, ga));
-    OSD_HIP(wgrad(s, W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C));
+    OSD_HIP(wgrad(s, W, W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C));
     OSD_HIP(dgrad(s, h->params[l2.w], C, C, W.g_z2[b], C, C, n, W.g_mid[b], C, false));
     // first half (dropout sits behind it)
     GnBwdArgs gb{};
     gb.g = W.g_mid[b]; gb.z = W.f.z1[b]; gb.stats = W.f.st1[b]; gb.gamma = h->params[l1.gamma]; gb.beta = h->params[l1.beta];
     gb.gz = W.g_z1[b]; gb.dgamma = grads[l1.gamma]; gb.dbeta = grads[l1.beta]; gb.dbias = grads[l1.b];
-    gb.rows = n; gb.C = C;
+    gb.rows = n; gb.C = C; gb.partials = W.partials;
     gb.drop_mode = drop ? (masks ? 1 : 2) : 0;
     gb.mask = (drop && masks) ? masks[b] : nullptr; gb.keep_scale = keep_scale; gb.p_drop = h->cfg.dropout_p;
     gb.seed = seed; gb.row_offset = roff; gb.step = 0; gb.tag = TAG_DROPOUT + (uint32_t)b;
     OSD_HIP(launch_gn_silu_bwd(s, l1.gw, gb));
     const int Kt = l1.K1 + l1.K2;
     const float* xin = (b == 0) ? W.f.h0 : W.f.out[b - 1];
-    OSD_HIP(wgrad(s, xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt));
+    OSD_HIP(wgrad(s, W, xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt));
     int skip_block = -1;
     if (l1.K2 > 0) {
       skip_block = a.n_enc - 1 - (b - a.n_enc - 1);
-      OSD_HIP(wgrad(s, W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt));
+      OSD_HIP(wgrad(s, W, W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt));
     }
     OSD_TRY(record());
     // dgrad into the producer of the main input; encoder outputs already hold their skip gradient
@@ -210,19 +231,19 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
     if (l1.K2 > 0) OSD_HIP(dgrad(s, h->params[l1.w] + l1.K1, Kt, l1.K2, W.g_z1[b], C, C, n, W.g_out[skip_block], l1.K2, false));
   }
   // input_proj, time_proj, cond_proj, ConditionalEmbedding  (h0 = x W^T + b + t_emb[t] + c_proj)
-  OSD_HIP(wgrad(s, W.x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D));
+  OSD_HIP(wgrad(s, W, W.x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D));
   OSD_HIP(launch_colsum(s, W.g_h0, a.H0, n, a.H0, grads[pm.in_b]));
   OSD_HIP(hipMemcpyAsync(grads[pm.cp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s));
   OSD_HIP(hipMemcpyAsync(grads[pm.tp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s));
   OSD_HIP(launch_scatter_rows(s, W.g_h0, t_idx, n, a.H0, W.g_temb));
-  OSD_HIP(wgrad(s, h->d_time_emb, a.time_dim, a.time_dim, W.g_temb, a.H0, a.H0, a.T, grads[pm.tp_w], a.time_dim));
-  OSD_HIP(wgrad(s, W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64));
+  OSD_HIP(wgrad(s, W, h->d_time_emb, a.time_dim, a.time_dim, W.g_temb, a.H0, a.H0, a.T, grads[pm.tp_w], a.time_dim));
+  OSD_HIP(wgrad(s, W, W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64));
   OSD_HIP(dgrad(s, h->params[pm.cp_w], 64, 64, W.g_h0, a.H0, a.H0, n, W.g_ce2, 64, false));
-  OSD_HIP(wgrad(s, W.f.ce1, 64, 64, W.g_ce2, 64, 64, n, grads[pm.ce2_w], 64));
+  OSD_HIP(wgrad(s, W, W.f.ce1, 64, 64, W.g_ce2, 64, 64, n, grads[pm.ce2_w], 64));
   OSD_HIP(launch_colsum(s, W.g_ce2, 64, n, 64, grads[pm.ce2_b]));
   OSD_HIP(dgrad(s, h->params[pm.ce2_w], 64, 64, W.g_ce2, 64, 64, n, W.g_ce1, 64, false));
   OSD_HIP(launch_silu_bwd(s, W.u0, W.g_ce1, W.g_u, n * 64));
-  OSD_HIP(wgrad(s, cond, a.cond_dim, a.cond_dim, W.g_u, 64, 64, n, grads[pm.ce0_w], a.cond_dim));
+  OSD_HIP(wgrad(s, W, cond, a.cond_dim, a.cond_dim, W.g_u, 64, 64, n, grads[pm.ce0_w], a.cond_dim));
   OSD_HIP(launch_colsum(s, W.g_u, 64, n, 64, grads[pm.ce0_b]));
   OSD_TRY(record());
   if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
