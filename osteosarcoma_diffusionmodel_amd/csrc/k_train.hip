@@ -183,14 +183,24 @@ __global__ __launch_bounds__(256) void k_gn_silu_bwd(GnBwdArgs a) {
   }
 }
 
-// out_q[c] = sum_b partials[b][q][c], q = 0..2 -> (dgamma, dbeta, dbias)
-__global__ void k_partial_reduce(const float* partials, int nb, int C, float* o0, float* o1, float* o2) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * C) return;
+// out_q[c] = sum_b partials[b][q][c], q = 0..2 -> (dgamma, dbeta, dbias).  64 columns per block, the
+// blocks-of-partials axis split over 4 thread rows (independent loads in flight), fixed summation order.
+__global__ __launch_bounds__(256) void k_partial_reduce(const float* partials, int nb, int C, float* o0, float* o1, float* o2) {
+  __shared__ float part[4][64];
+  const int cx = threadIdx.x & 63, bp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + cx;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += partials[(size_t)b * 3 * C + i];
-  const int q = i / C, c = i - q * C;
-  (q == 0 ? o0 : q == 1 ? o1 : o2)[c] = s;
+  if (i < 3 * C) {
+#pragma unroll 8
+    for (int b = bp; b < nb; b += 4) s += partials[(size_t)b * 3 * C + i];
+  }
+  part[bp][cx] = s;
+  __syncthreads();
+  if (bp == 0 && i < 3 * C) {
+    const float v = (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]);
+    const int q = i / C, c = i - q * C;
+    (q == 0 ? o0 : q == 1 ? o1 : o2)[c] = v;
+  }
 }
 
 int gn_bwd_blocks(int64_t rows) {
@@ -212,7 +222,7 @@ static hipError_t gn_bwd_go(hipStream_t s, const GnBwdArgs& a) {
     case 4: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 4>), blocks, 256, lds, s, a); break;
     default: return hipErrorInvalidValue;
   }
-  hipLaunchKernelGGL(k_partial_reduce, (3 * a.C + 255) / 256, 256, 0, s, a.partials, blocks, a.C, a.dgamma, a.dbeta, a.dbias);
+  hipLaunchKernelGGL(k_partial_reduce, (3 * a.C + 63) / 64, 256, 0, s, a.partials, blocks, a.C, a.dgamma, a.dbeta, a.dbias);
   return hipGetLastError();
 }
 hipError_t launch_gn_silu_bwd(hipStream_t s, int gw, const GnBwdArgs& a) {
