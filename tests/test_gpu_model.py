@@ -200,3 +200,43 @@ def test_errors_are_python_exceptions():
         m.p_sample(torch.zeros(2, 2000, device="cuda"), 1000, torch.zeros(2, 3, device="cuda"))
     with pytest.raises(RuntimeError):
         m.sample(torch.zeros(2, 3), 2)                               # CPU tensor, GPU model
+
+
+@pytest.mark.parametrize("dims,hidden,cond_dim", [
+    ((62, 5054, 26), [256, 512, 256], 3),      # the reference's real TARGET-OS shape: D = 5142, rows not 16-byte aligned
+    ((5, 30, 3), [64, 128, 256, 64], 4),       # 4 hidden dims, cond_dim 4, D = 38 (D % 4 != 0), group widths 8/16/32
+    ((10, 54, 0), [32], 2),                    # single hidden dim: bottleneck only, no encoder/decoder, no pathways
+])
+def test_odd_shapes_vs_oracle(dims, hidden, cond_dim):
+    """Unaligned / odd extents take the guarded (non-FAST) kernel paths: chain, single step and
+    training gradients against the oracle."""
+    T = 12
+    conf = config(hidden, T=T)
+    shapes = O.param_shapes(*dims, cond_dim, hidden, 128)
+    sd = O.init_state_dict(shapes, seed=21)
+    gen = torch.Generator().manual_seed(5)
+    for k in sd:
+        if k.endswith((".1.weight", ".5.weight")) and sd[k].dim() == 1:
+            sd[k] = 1 + 0.2 * torch.randn(sd[k].shape, generator=gen)
+    m = BiologyAwareDiffusionModel(*dims, cond_dim, conf)
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda().eval()
+    D, n = sum(dims), 37
+    cond = torch.randn(n, cond_dim, generator=gen)
+    x_T = torch.randn(n, D, generator=gen)
+    zs = torch.randn(T - 1, n, D, generator=gen)
+    bufs = O.schedule_buffers("cosine", T)
+    nh = len(hidden)
+    ref = O.sample(sd, bufs, cond, x_T, lambda t: zs[T - 1 - t], nh, 128)
+    out = m.sample(cond.cuda(), n, x_T=x_T.cuda(), noise=zs.cuda())
+    assert_close(out.cpu(), ref, CHAIN_RTOL, what=f"chain {dims} {hidden}")
+    # training gradients (eval mode: no dropout) through the autograd interface
+    t = torch.randint(0, T, (n,), generator=gen)
+    noise = torch.randn(n, D, generator=gen)
+    x0 = torch.randn(n, D, generator=gen)
+    ref_loss, ref_grads = O.training_loss_and_grads(sd, bufs, x0, cond, t, noise, nh, 128)
+    loss = m(x0.cuda(), cond.cuda(), t=t.cuda(), noise=noise.cuda())
+    loss.backward()
+    assert_close(loss.item(), ref_loss, 1e-5, what="loss")
+    for k, p in m.named_parameters():
+        assert_close(p.grad.cpu(), ref_grads[k], 5e-5, atol=1e-8, what=f"grad {k}")
