@@ -169,6 +169,25 @@ int osd_clip_adamw_step(osd_handle *h, float *param, float *grad, float *exp_avg
 int osd_profile_step(osd_handle *h, const float *cond, int64_t n, int reps, float *ms_out,
                      double *flop_out, int max_entries, int *n_entries);
 
+/* ---- validation metrics on the device (utils/validation.py) ----------------
+ * Stream/device based (no model handle), synchronous: results are host scalars. */
+/* compute_mmd (utils/validation.py:273-298): RBF kernel, gamma <= 0 -> 1/D, means over all pairs
+ * including the diagonal, sqrt(max(XX + YY - 2 XY, 0)).  X dev [n][D], Y dev [m][D]. */
+int osd_val_mmd(void *stream, int device, const float *X, int64_t n, const float *Y, int64_t m, int D,
+                double gamma, double *mmd_out);
+/* scipy.stats.ks_2samp as used at utils/validation.py:238-245, for features 0..nf-1 of real dev [n1][ld]
+ * and synth dev [n2][ld]: exact integer extremes of cnt(real<=v)*n2 - cnt(synth<=v)*n1 over all sample
+ * points v; the statistic is max(dmax, -dmin, 0) / (n1*n2) (p-values follow on the host). */
+int osd_val_ks_extremes(void *stream, int device, const float *real, int64_t n1, const float *synth,
+                        int64_t n2, int ld, int nf, int64_t *dmax_out, int64_t *dmin_out);
+/* Mean of the strict upper triangle of the Pearson matrix of data[:, cols] (utils/validation.py:156-161);
+ * cols: host array of g column indices, 2 <= g <= 512. */
+int osd_val_mean_offdiag_corr(void *stream, int device, const float *data, int64_t rows, int ld,
+                              const int32_t *cols_host, int g, double *out);
+/* Pearson correlation of two strided device columns (Series.corr at utils/validation.py:205). */
+int osd_val_pearson(void *stream, int device, const float *a, int lda, const float *b, int ldb,
+                    int64_t rows, double *out);
+
 /* ---- building blocks, exported for the parity tests ------------------------ */
 /* y[n][N] = act(x[n][K] @ w[N][K]^T + b), act = identity (silu=0) or SiLU. */
 int osd_op_linear(osd_handle *h, const float *x, const float *w, const float *b, int64_t n, int K,

@@ -47,6 +47,10 @@ _SIGNATURES = {
     "osd_mixup": (C.c_int, [_P, _P, _P, _P, _P, C.c_double, C.c_int64, _P, _P, _P]),
     "osd_clip_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
                                       C.c_double, C.c_double, C.c_int64, _P]),
+    "osd_val_mmd": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.c_int64, C.c_int, C.c_double, C.POINTER(C.c_double)]),
+    "osd_val_ks_extremes": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "osd_val_mean_offdiag_corr": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
+    "osd_val_pearson": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int64, C.POINTER(C.c_double)]),
     "osd_profile_step": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
     "osd_op_linear": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     "osd_op_linear_gn_silu": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int, _P]),

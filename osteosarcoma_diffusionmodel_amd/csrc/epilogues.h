@@ -292,4 +292,40 @@ struct EpiMse {
   }
 };
 
+// ---- RBF-kernel sum for the MMD metric (utils/validation.py:287-296) -------------------------------
+// acc = x_f . y_p;  d2 = |x_f|^2 + |y_p|^2 - 2 acc;  sum += exp(-gamma * max(d2, 0)) over the valid tile
+struct EpiRbfSum {
+  template <class A> static __device__ __forceinline__ void slice(A&, int) {}
+  struct Args { const float* sqa; const float* sqb; float gamma; double* sum; };
+  static bool fast_ok(const Args& a, int F) { return F % 4 == 0 && al16(a.sqa); }
+  template <int NFB, int NPB, bool FAST>
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, int fw, int pw, int lane, int F, int P) {
+    const int l31 = lane & 31, h = lane >> 5;
+    float part = 0.f;
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+      const int p = pw + 32 * pb + l31;
+      const float sb = a.sqb[p < P ? p : P - 1];
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int f = fw + 32 * fb + 8 * q + 4 * h;
+          const float4 sa = ldq<FAST>(a.sqa, f, F);
+          const float sav[4] = {sa.x, sa.y, sa.z, sa.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d2 = fmaxf(sav[r] + sb - 2.0f * acc[fb][pb][4 * q + r], 0.f);
+            const float k = expf(-a.gamma * d2);
+            part += (p < P && f + r < F) ? k : 0.f;
+          }
+        }
+    }
+    double dp = (double)part;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dp += __shfl_xor(dp, o);
+    if (lane == 0) atomicAdd(a.sum, dp);
+  }
+};
+
 }  // namespace osd

@@ -367,8 +367,62 @@ def g8():
          init_seed=np.asarray(1234), noise_pred=pred.numpy(), p_sample_640=step.numpy())
 
 
+def g9():
+    """Validation metrics (utils/validation.py): MMD, KS, pathway coherence, mutation-expression sign check."""
+    import pandas as pd
+    import yaml
+    from utils.validation import BiologicalValidator
+    conf = yaml.safe_load(open(REF / "config" / "config.yaml"))
+    val = BiologicalValidator(conf)
+    rs = np.random.RandomState(11)
+    out = {}
+    # MMD + KS on [n, D] arrays (real vs shifted synthetic)
+    real = rs.randn(90, 130).astype(np.float32)
+    synth = (rs.randn(70, 130) * 1.1 + 0.15).astype(np.float32)
+    synth[:, :20] = real[rs.randint(0, 90, 70), :20]            # ties between the two samples
+    out["real"], out["synth"] = real, synth
+    out["mmd"] = np.float64(val.compute_mmd(real, synth))
+    out["mmd_same"] = np.float64(val.compute_mmd(real, real))
+    st = val.statistical_tests(real, synth)
+    for k in ("ks_test_mean_pvalue", "ks_test_fraction_significant", "mmd"):
+        out[f"stat.{k}"] = np.float64(st[k])
+    from scipy import stats as sps
+    ks = [sps.ks_2samp(real[:, i], synth[:, i]) for i in range(100)]
+    out["ks_stat"] = np.array([k.statistic for k in ks])
+    out["ks_pvalue"] = np.array([k.pvalue for k in ks])
+    # pathway coherence: 12 pathways over 40 genes (first 10 used; one with < 3 genes present is skipped)
+    genes = [f"G{i}" for i in range(40)]
+    base = rs.randn(90, 6)
+    load = rs.randn(6, 40) * (rs.rand(6, 40) < 0.3)
+    real_e = (base @ load + 0.7 * rs.randn(90, 40)).astype(np.float32)
+    synth_e = (rs.randn(70, 6) @ load + 0.9 * rs.randn(70, 40)).astype(np.float32)
+    member = (rs.rand(45, 12) < 0.25).astype(int)                # 45 genes listed, 5 of them absent from the data
+    member[:, 3] = 0
+    member[[1, 2], 3] = 1                                        # pathway 3: only 2 genes -> skipped
+    pgm = pd.DataFrame(member, index=[f"G{i}" for i in range(45)], columns=[f"P{i}" for i in range(12)])
+    coh = val.validate_pathway_coherence(pd.DataFrame(real_e, columns=genes), pd.DataFrame(synth_e, columns=genes), pgm)
+    out["coh_real"], out["coh_synth"], out["coh_member"] = real_e, synth_e, member
+    for k, v in coh.items():
+        out[f"coh.{k}"] = np.float64(v)
+    # mutation-expression sign rules of config.yaml:110-116
+    mut = pd.DataFrame((rs.rand(70, 3) < 0.4).astype(float), columns=["TP53", "MYC", "RB1"])
+    pw = pd.DataFrame(rs.randn(70, 2), columns=["HALLMARK_P53_PATHWAY", "HALLMARK_MYC_TARGETS_V1"])
+    pw["HALLMARK_P53_PATHWAY"] += 0.8 * mut["TP53"]              # positive although "negative" is required -> violation
+    pw["HALLMARK_MYC_TARGETS_V1"] += 0.8 * mut["MYC"]            # positive as required
+    me = val.validate_mutation_expression_correlation(mut, None, pw)
+    out["me_mut"], out["me_pw"] = mut.values, pw.values
+    out["me.violation_rate"] = np.float64(me["mutation_expression_violation_rate"])
+    out["me.corr"] = np.array([mut["TP53"].corr(pw["HALLMARK_P53_PATHWAY"]), mut["MYC"].corr(pw["HALLMARK_MYC_TARGETS_V1"])])
+    save("g9_validation", **out)
+
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3_g4(); g5(); g6(); g7(); g8()
+    if len(sys.argv) > 1:
+        for name in sys.argv[1:]:
+            globals()[name]()
+    else:
+        g1(); g2(); g3_g4(); g5(); g6(); g7(); g8(); g9()
     # leave nothing behind in the read-only reference tree
     for pc in REF.rglob("__pycache__"):
         print("WARNING: bytecode dir appeared:", pc)

@@ -191,3 +191,25 @@ def test_g8_full_shape(golden_dir):
     close(pred, g["noise_pred"], rtol=2e-6)
     bufs = O.schedule_buffers("cosine", 1000)
     close(O.p_sample(sd, bufs, x, 640, cond, z, 3, 128), g["p_sample_640"], rtol=2e-6)
+
+
+def test_g9_validation_metrics(golden_dir):
+    """oracle/validation_oracle.py against the reference's BiologicalValidator outputs."""
+    from oracle import validation_oracle as V
+    g = load(golden_dir, "g9_validation")
+    real, synth = g["real"], g["synth"]
+    assert abs(V.mmd_rbf(real, synth) - g["mmd"]) < 1e-9
+    assert V.mmd_rbf(real, real) < 1e-6 and g["mmd_same"] < 1e-6
+    for i in range(100):
+        dmax, dmin = V.ks_count_extremes(real[:, i], synth[:, i])
+        d, p = V.ks_pvalue(90, 70, dmax, dmin)
+        assert abs(d - g["ks_stat"][i]) < 1e-12 and abs(p - g["ks_pvalue"][i]) < 1e-12
+    ks = V.ks_summary(real, synth)
+    assert abs(ks["ks_test_mean_pvalue"] - g["stat.ks_test_mean_pvalue"]) < 1e-12
+    assert ks["ks_test_fraction_significant"] == g["stat.ks_test_fraction_significant"]
+    coh = V.pathway_coherence(g["coh_real"], g["coh_synth"], g["coh_member"], 40)
+    for k, v in coh.items():
+        assert abs(v - g["coh." + k]) < 1e-6, k
+    c = [V.pearson(g["me_mut"][:, 0], g["me_pw"][:, 0]), V.pearson(g["me_mut"][:, 1], g["me_pw"][:, 1])]
+    assert np.allclose(c, g["me.corr"], atol=1e-12)
+    assert V.violation_rate(c, ["negative", "positive"]) == g["me.violation_rate"]
