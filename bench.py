@@ -86,12 +86,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # rehearsal knobs (single-GPU box): OSD_BENCH_BACKEND=gloo, OSD_BENCH_ONE_DEVICE=1 put every rank on cuda:0
+    backend = os.environ.get("OSD_BENCH_BACKEND", "nccl")
+    if os.environ.get("OSD_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel, _lib as L
@@ -130,7 +137,7 @@ def main():
     fence()
     elapsed = max(time.perf_counter() - t0, 1e-9)
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if args.steps:

@@ -1,0 +1,87 @@
+"""GPU: data-parallel Trainer step with 2 ranks (both on cuda:0, gloo carrying the CUDA all-reduce, which
+exercises the same code path as RCCL: per-bucket events recorded by osd_train_loss_fwd_bwd, comm stream,
+gradients pre-scaled by 1/world).  Two ranks on half batches must reproduce one process on the full batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+SM = dict(mutation_dim=8, expression_dim=24, pathway_dim=8, condition_dim=3)
+
+
+def _conf(save_dir):
+    return {"model": {"latent_dim": 128, "hidden_dims": [32, 64, 32], "gnn": {"dropout": 0.0},
+                      "diffusion": {"num_steps": 100, "beta_schedule": "cosine"}, "condition_on": []},
+            "training": {"learning_rate": 1e-3, "weight_decay": 1e-5, "patience": 100, "min_delta": 1e-4,
+                         "augmentation": {"mixup_alpha": 0.0}, "save_dir": save_dir, "num_epochs": 1,
+                         "save_frequency": 10, "val_split": 0.2, "random_seed": 42, "batch_size": 32}}
+
+
+def _data():
+    g = torch.Generator().manual_seed(0)
+    B = 64
+    return (torch.randn(B, 40, generator=g), torch.randn(B, 3, generator=g),
+            torch.randint(0, 100, (B,), generator=g), torch.randn(B, 40, generator=g))
+
+
+def _worker(rank, world, port, save_dir, q):
+    import torch.distributed as dist
+    from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel
+    from osteosarcoma_diffusionmodel_amd.train import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        m = BiologyAwareDiffusionModel(config=_conf(save_dir), **SM)
+        tr = Trainer(m, [], [], _conf(save_dir), device="cuda")
+        assert tr.dist and tr.world == world and tr._events is not None
+        m.train()
+        x, c, t, nz = _data()
+        half = x.shape[0] // world
+        sl = slice(rank * half, (rank + 1) * half)
+        losses = []
+        for _ in range(3):
+            losses.append(tr.train_step(x[sl].cuda(), c[sl].cuda(), t=t[sl].cuda(), noise=nz[sl].cuda()).item())
+        torch.cuda.synchronize()
+        q.put((rank, losses, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process(tmp_path):
+    from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel
+    from osteosarcoma_diffusionmodel_amd.train import Trainer
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    # single process, full batch
+    torch.manual_seed(0)
+    m = BiologyAwareDiffusionModel(config=_conf(str(tmp_path)), **SM)
+    tr = Trainer(m, [], [], _conf(str(tmp_path)), device="cuda")
+    m.train()
+    x, c, t, nz = _data()
+    ref_losses = [tr.train_step(x.cuda(), c.cuda(), t=t.cuda(), noise=nz.cuda()).item() for _ in range(3)]
+    ref = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    # both ranks hold identical parameters, equal to the single-process ones
+    for k in ref:
+        assert np.array_equal(res[0][2][k], res[1][2][k]), f"ranks diverged on {k}"
+        tol = 2e-5 * max(np.abs(ref[k]).max(), 1e-6)
+        assert np.abs(res[0][2][k] - ref[k]).max() <= tol, k
+    # the global loss is the mean of the two shard losses
+    for i in range(3):
+        assert abs(0.5 * (res[0][1][i] + res[1][1][i]) - ref_losses[i]) < 1e-5 * abs(ref_losses[i])
