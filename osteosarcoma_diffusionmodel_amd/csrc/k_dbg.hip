@@ -163,3 +163,88 @@ extern "C" int osd_dbg_census(osd_handle* h, int grid, unsigned* out) {
   OSD_HIP(hipStreamSynchronize(h->stream));
   return OSD_OK;
 }
+
+// ---- variant: BK = 16, three LDS stages, DMA two tiles ahead with a counted vmcnt ------------------
+namespace osd {
+template <int STAGES>
+__global__ __launch_bounds__(256, 2) void k_mfma_rate16(const float* src, float* dst, int nk16) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wf = (wave >> 1) * 64, wp = (wave & 1) * 64;
+  constexpr int TILE = 128 * 16;            // floats per operand tile
+  for (int i = tid; i < STAGES * 2 * TILE; i += 256) smem[i] = (float)((i * 7) % 13) * 0.01f;
+  __syncthreads();
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int a_rd[2], a_sw[2], b_rd[2], b_sw[2];
+  for (int fb = 0; fb < 2; ++fb) { const int R = wf + 32 * fb + l31; a_rd[fb] = R * 16; a_sw[fb] = h ^ ((R >> 2) & 3); }
+  for (int pb = 0; pb < 2; ++pb) { const int R = wp + 32 * pb + l31; b_rd[pb] = R * 16; b_sw[pb] = h ^ ((R >> 2) & 3); }
+  const float* xrow[2];
+  for (int j = 0; j < 2; ++j) {
+    const int row = (j * 4 + wave) * 16 + (lane >> 2);
+    xrow[j] = src + 65536 + ((size_t)blockIdx.x * 128 + row) * 2000 + 4 * ((lane & 3) ^ ((row >> 2) & 3));
+  }
+  const float* gbase = src + (size_t)(blockIdx.x % 64) * 4096 + (wave * 64 + lane) * 4;
+  auto stage = [&](int kt) {
+    const int st = kt % STAGES;
+    const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr(smem + st * 2 * TILE) + (unsigned)wave * 1024u);
+    const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(smem + st * 2 * TILE + TILE) + (unsigned)wave * 1024u);
+    const int k0 = (kt % 124) * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { glds16(gbase + j * 1024 + (kt & 7) * 2048, la + j * 4096u); glds16(xrow[j] + k0, lb + j * 4096u); }
+  };
+  for (int p = 0; p < STAGES - 1; ++p) stage(p);
+  if (STAGES == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nk16; ++kt) {
+    const float* Ac = smem + (kt % STAGES) * 2 * TILE;
+    const float* Bc = Ac + TILE;
+    stage(kt + STAGES - 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float a[2][4], bb[2][4];
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb) { const float4 t = *reinterpret_cast<const float4*>(&Ac[a_rd[fb] + 4 * (a_sw[fb] ^ (2 * i))]); a[fb][0] = t.x; a[fb][1] = t.y; a[fb][2] = t.z; a[fb][3] = t.w; }
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) { const float4 t = *reinterpret_cast<const float4*>(&Bc[b_rd[pb] + 4 * (b_sw[pb] ^ (2 * i))]); bb[pb][0] = t.x; bb[pb][1] = t.y; bb[pb][2] = t.z; bb[pb][3] = t.w; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) acc[fb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fb][e], bb[pb][e], acc[fb][pb], 0, 0, 0);
+    }
+    // tile kt+1 must have landed; the 4 DMAs of tile kt+2 (just issued) may stay in flight
+    if (STAGES == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  float s = 0.f;
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  dst[blockIdx.x * 256 + tid] = s;
+}
+}  // namespace osd
+extern "C" int osd_dbg_mfma_rate16(osd_handle* h, int stages, int nk16, int grid, const float* src, float* dst, float* ms_out) {
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  hipEvent_t e0, e1;
+  OSD_HIP(hipEventCreate(&e0));
+  OSD_HIP(hipEventCreate(&e1));
+  const int lds = stages * 2 * 128 * 16 * 4;
+  auto run = [&]() {
+    if (stages == 3) hipLaunchKernelGGL((osd::k_mfma_rate16<3>), grid, 256, lds, h->stream, src, dst, nk16);
+    else hipLaunchKernelGGL((osd::k_mfma_rate16<2>), grid, 256, lds, h->stream, src, dst, nk16);
+  };
+  run();
+  OSD_HIP(hipEventRecord(e0, h->stream));
+  for (int i = 0; i < 5; ++i) run();
+  OSD_HIP(hipEventRecord(e1, h->stream));
+  OSD_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  OSD_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / 5;
+  OSD_HIP(hipEventDestroy(e0));
+  OSD_HIP(hipEventDestroy(e1));
+  return OSD_OK;
+}

@@ -6,6 +6,7 @@ namespace osd {
 
 hipError_t launch_input(hipStream_t s, const GemmArgs& g, const EpiInput::Args& a, bool a_zero_padded) {
   if (use_big_tile(g.F, g.P)) return launch_gemm<TileBig, true, true, EpiInput>(s, g, a, a_zero_padded);
+  if (use_tile64(g.F, g.P)) return launch_gemm<Tile64, true, true, EpiInput>(s, g, a, a_zero_padded);
   return launch_gemm<TileSmall, true, true, EpiInput>(s, g, a, a_zero_padded);
 }
 hipError_t launch_posterior(hipStream_t s, const GemmArgs& g, const EpiPosterior::Args& a) {

@@ -13,6 +13,9 @@ static hipError_t gn_go(hipStream_t s, const GemmArgs& g, const GnArgs& a) {
     return launch_gemm<TileWide, true, true, E>(s, g, ea);
   } else {
     if (use_big_tile(g.F, g.P)) return launch_gemm<TileBig, true, true, E>(s, g, ea);
+    if constexpr (GW <= 32) {
+      if (use_tile64(g.F, g.P)) return launch_gemm<Tile64, true, true, E>(s, g, ea);      // 32-feature waves own whole groups
+    }
     return launch_gemm<TileSmall, true, true, E>(s, g, ea);
   }
 }

@@ -21,6 +21,11 @@ inline bool use_big_tile(int F, int P) {
   const long tiles = (long)((F + 127) / 128) * ((P + 127) / 128);
   return tiles >= 256;
 }
+// training-sized batches: true when even the 64x128 tile leaves CUs idle and 64x64 tiles should be used
+inline bool use_tile64(int F, int P) {
+  const long tiles = (long)((F + 63) / 64) * ((P + 127) / 128);
+  return tiles < 256;
+}
 
 // Every instantiation registers itself at load time; prepare_kernels() (called from
 // osd_create, never inside a stream capture) raises each kernel's dynamic-LDS limit.

@@ -58,7 +58,7 @@ static hipError_t wgrad(hipStream_t s, const TrainWs& w, const float* x, int ldx
   GemmArgs g{};
   g.A = x; g.lda = ldx; g.B0 = gz; g.ldb0 = ldg; g.K0 = (int)rows; g.F = kin; g.P = nout; g.K = (int)rows;
   const long tiles = (long)((kin + 63) / 64) * ((nout + 63) / 64);
-  int slices = (int)((1024 + tiles - 1) / tiles);
+  int slices = (int)((512 + tiles - 1) / tiles);
   const int max_slices = (int)((rows + 127) / 128);
   if (slices > max_slices) slices = max_slices;
   const int64_t numel = (int64_t)nout * kin;

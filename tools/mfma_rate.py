@@ -19,9 +19,20 @@ src = torch.randn(65536 + 1024 * 128 * 2000 + 4096, device="cuda")
 dst = torch.zeros(1024 * 128 * 512, device="cuda")
 names = {0: "MFMA only", 1: "+LDS fragment reads", 2: "+barrier/step", 3: "+glds DMA (L2-hot)", 4: "+glds DMA (x rows from HBM)", 5: "+DMA +quad stores [p][f]", 6: "+DMA +row stores"}
 for grid in (512, 1024):
-    for mode in (2, 3, 5, 6):
-        for nk in (8, 16):
+    for mode in (3, 4):
+        for nk in (8, 64):
             ms = C.c_float()
             L.check(fn(rh.h, mode, nk, grid, L.ptr(src), L.ptr(dst), C.byref(ms)))
             flops = grid * 4 * 64 * nk * 4096.0       # waves * MFMAs/step * steps * flop/MFMA
             print(f"grid={grid:5d} nk={nk:3d} {names[mode]:22s} {ms.value*1e3:9.1f} us  {flops/ms.value/1e9:7.1f} TFLOP/s")
+
+fn16 = lib.osd_dbg_mfma_rate16
+fn16.restype = C.c_int
+fn16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+for grid in (512, 1024):
+    for stages in (2, 3):
+        for nk in (16, 128):
+            ms = C.c_float()
+            L.check(fn16(rh.h, stages, nk, grid, L.ptr(src), L.ptr(dst), C.byref(ms)))
+            flops = grid * 4 * 32 * nk * 4096.0
+            print(f"grid={grid:5d} nk16={nk:3d} BK=16 {stages}-stage DMA (x rows from HBM)  {ms.value*1e3:9.1f} us  {flops/ms.value/1e9:7.1f} TFLOP/s")
