@@ -240,3 +240,40 @@ def test_odd_shapes_vs_oracle(dims, hidden, cond_dim):
     assert_close(loss.item(), ref_loss, 1e-5, what="loss")
     for k, p in m.named_parameters():
         assert_close(p.grad.cpu(), ref_grads[k], 5e-5, atol=1e-8, what=f"grad {k}")
+
+
+def test_c_abi_error_codes():
+    """The C ABI reports misuse through return codes + osd_last_error (never aborts): call order, bad
+    arguments, unsupported architectures."""
+    import ctypes as C
+    from osteosarcoma_diffusionmodel_amd import _lib as L
+    lib = L.lib()
+    cfg = L.OsdConfig()
+    cfg.mutation_dim, cfg.expression_dim, cfg.pathway_dim, cfg.condition_dim = 8, 24, 8, 3
+    cfg.time_dim, cfg.n_hidden, cfg.num_steps, cfg.dropout_p, cfg.device = 128, 3, 10, 0.0, 0
+    for i, v in enumerate((32, 64, 32)):
+        cfg.hidden_dims[i] = v
+    h = C.c_void_p()
+    assert lib.osd_create(C.byref(cfg), C.byref(h)) == L.OSD_OK
+    x = torch.zeros(4, 40, device="cuda")
+    c = torch.zeros(4, 3, device="cuda")
+    # weights before schedule, compute before weights
+    arr = (C.c_void_p * 52)(*[x.data_ptr()] * 52)
+    assert lib.osd_load_weights(h, arr, 52) == L.OSD_ESTATE and b"osd_set_schedule" in lib.osd_last_error()
+    assert lib.osd_p_sample_step(h, L.ptr(x), 3, L.ptr(c), None, 4, 0, 0, L.ptr(x), 0) == L.OSD_ESTATE
+    assert lib.osd_sample_chain(h, L.ptr(c), 4, None, None, 0, 0, L.ptr(x), None, 0) == L.OSD_ESTATE
+    assert lib.osd_load_weights(h, arr, 51) == L.OSD_EINVAL
+    assert lib.osd_set_option(h, b"chunk_rows", 0) == L.OSD_EINVAL and lib.osd_set_option(h, b"nope", 1) == L.OSD_EINVAL
+    assert lib.osd_set_option(h, b"n_streams", 3) == L.OSD_OK
+    assert lib.osd_destroy(h) == L.OSD_OK
+    cfg.hidden_dims[1] = 24                          # divisible by 8 but group width 3: outside the fused kernels
+    assert lib.osd_create(C.byref(cfg), C.byref(h)) == L.OSD_EUNSUPPORTED
+    cfg.hidden_dims[1] = 20                          # not divisible by 8: GroupNorm(8, C) itself rejects it
+    assert lib.osd_create(C.byref(cfg), C.byref(h)) == L.OSD_EINVAL
+    cfg.hidden_dims[1] = 64
+    cfg.device = 99
+    assert lib.osd_create(C.byref(cfg), C.byref(h)) == L.OSD_EINVAL
+    with pytest.raises(ValueError):                  # same conditions through the Python mirror
+        BiologyAwareDiffusionModel(config=config([32, 24, 32]), **SM).cuda().sample(torch.zeros(1, 3, device="cuda"), 1)
+    with pytest.raises(ValueError):
+        BiologyAwareDiffusionModel(config=config([32, 20, 32]), **SM)
