@@ -26,11 +26,11 @@ std::vector<KernelReg>& kernel_registry() {
   static std::vector<KernelReg> r;
   return r;
 }
-int stagger_mode() {
+int persist_mode() {
   static int mode = -1;
   if (mode < 0) {
-    const char* e = getenv("OSD_STAGGER");
-    mode = e ? atoi(e) : 1;
+    const char* e = getenv("OSD_PERSIST");
+    mode = e ? atoi(e) : 0;       // measured: with two chunks in flight the one-tile-per-workgroup grid is faster
   }
   return mode;
 }

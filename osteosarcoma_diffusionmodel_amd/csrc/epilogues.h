@@ -19,23 +19,44 @@ __device__ __forceinline__ float silu_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// value of lane^32 (the other half-wave), through v_permlane32_swap instead of an LDS bpermute
+__device__ __forceinline__ float swap_halves(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  // after the swap: r[0] holds {own low half | partner's low half -> upper lanes ...}; lane < 32 reads r[1]'s low, lane >= 32 reads r[0]'s high
+  return __uint_as_float((__lane_id() < 32) ? r[1] : r[0]);
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- bias (+ optional SiLU, + optional accumulate into out) -----------------------
 template <bool SILU, bool ACCUM>
 struct EpiBias {
+  static constexpr bool COUNTED_STORES = true;    // one float4 store per accumulator quad on a full tile
   struct Args { const float* bias; float* out; int ldo; long long slice_stride; };
   static bool fast_ok(const Args& a, int F) { return F % 4 == 0 && al16(a.bias) && al16(a.out) && a.ldo % 4 == 0 && a.slice_stride % 4 == 0; }
   static __device__ __forceinline__ void slice(Args& a, int y) { a.out += (long long)y * a.slice_stride; }
+  template <int NFB> struct Pre { float4 bias[NFB][4]; };
+  template <int NFB, bool FAST>
+  static __device__ __forceinline__ Pre<NFB> prefetch(const Args& a, int fw, int lane, int F) {
+    Pre<NFB> r;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        r.bias[fb][q] = a.bias ? ldq<FAST>(a.bias, fw + 32 * fb + 8 * q + 4 * h, F) : make_float4(0.f, 0.f, 0.f, 0.f);
+    return r;
+  }
   template <int NFB, int NPB, bool FAST>
-  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, int fw, int pw, int lane, int F, int P) {
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P) {
     const int l31 = lane & 31, h = lane >> 5;
     OSD_FOR_QUADS(fb, pb, q) {
       const int f = fw + 32 * fb + 8 * q + 4 * h;
       const int p = pw + 32 * pb + l31;
       const int pc = p < P ? p : P - 1;
       float4 v = make_float4(acc[fb][pb][4 * q], acc[fb][pb][4 * q + 1], acc[fb][pb][4 * q + 2], acc[fb][pb][4 * q + 3]);
-      if (a.bias) { const float4 bv = ldq<FAST>(a.bias, f, F); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+      { const float4 bv = pre.bias[fb][q]; v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
       float* row = a.out + (size_t)pc * a.ldo;
       if (ACCUM) { const float4 o = ldq<FAST>(row, f, F); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
       if (SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
@@ -46,6 +67,7 @@ struct EpiBias {
 
 // ---- input_proj: h = ((x W^T + b) + t_emb[t]) + c_proj   (models/diffusion.py:229-232) ----
 struct EpiInput {
+  static constexpr bool COUNTED_STORES = true;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias;
@@ -58,8 +80,19 @@ struct EpiInput {
   static bool fast_ok(const Args& a, int F) {
     return F % 4 == 0 && al16(a.bias) && al16(a.temb) && al16(a.cproj) && al16(a.out) && a.ldt % 4 == 0 && a.ldc % 4 == 0 && a.ldo % 4 == 0;
   }
+  template <int NFB> struct Pre { float4 bias[NFB][4]; };
+  template <int NFB, bool FAST>
+  static __device__ __forceinline__ Pre<NFB> prefetch(const Args& a, int fw, int lane, int F) {
+    Pre<NFB> r;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r.bias[fb][q] = ldq<FAST>(a.bias, fw + 32 * fb + 8 * q + 4 * h, F);
+    return r;
+  }
   template <int NFB, int NPB, bool FAST>
-  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, int fw, int pw, int lane, int F, int P) {
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P) {
     const int l31 = lane & 31, h = lane >> 5;
     const int t_shared = a.t_dev ? *a.t_dev : a.t_imm;
 #pragma unroll
@@ -75,7 +108,7 @@ struct EpiInput {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int f = fw + 32 * fb + 8 * q + 4 * h;
-          const float4 bv = ldq<FAST>(a.bias, f, F), tv = ldq<FAST>(trow, f, F), cv = ldq<FAST>(crow, f, F);
+          const float4 bv = pre.bias[fb][q], tv = ldq<FAST>(trow, f, F), cv = ldq<FAST>(crow, f, F);
           float4 v;
           v.x = ((acc[fb][pb][4 * q] + bv.x) + tv.x) + cv.x;
           v.y = ((acc[fb][pb][4 * q + 1] + bv.y) + tv.y) + cv.y;
@@ -96,6 +129,7 @@ struct EpiInput {
 // (mean, rstd) for backward.
 template <int GW, bool DROP>
 struct EpiGnSilu {
+  static constexpr bool COUNTED_STORES = true;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias; const float* gamma; const float* beta;
@@ -112,8 +146,25 @@ struct EpiGnSilu {
     return F % 4 == 0 && al16(a.bias) && al16(a.gamma) && al16(a.beta) && al16(a.out) && a.ldo % 4 == 0 &&
            (!a.z_out || (al16(a.z_out) && a.ldz % 4 == 0)) && (a.drop_mode != 1 || (al16(a.mask) && a.ldm % 4 == 0));
   }
+  // per-feature parameters of this lane's quads: fetched before the K loop so their latency is hidden
+  template <int NFB> struct Pre { float4 bias[NFB][4], gamma[NFB][4], beta[NFB][4]; };
+  template <int NFB, bool FAST>
+  static __device__ __forceinline__ Pre<NFB> prefetch(const Args& a, int fw, int lane, int F) {
+    Pre<NFB> r;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = fw + 32 * fb + 8 * q + 4 * h;
+        r.bias[fb][q] = ldq<FAST>(a.bias, f, F);
+        r.gamma[fb][q] = ldq<FAST>(a.gamma, f, F);
+        r.beta[fb][q] = ldq<FAST>(a.beta, f, F);
+      }
+    return r;
+  }
   template <int NFB, int NPB, bool FAST>
-  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, int fw, int pw, int lane, int F, int P) {
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P) {
     static_assert(NFB * 32 >= GW, "wave must own whole groups");
     constexpr int RPG = (GW >= 8) ? GW / 2 : 4;   // registers of one group in this lane
     constexpr int NG = NFB * 16 / RPG;
@@ -123,8 +174,7 @@ struct EpiGnSilu {
     for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int f = fw + 32 * fb + 8 * q + 4 * h;
-        const float4 bv = ldq<FAST>(a.bias, f, F);
+        const float4 bv = pre.bias[fb][q];
 #pragma unroll
         for (int pb = 0; pb < NPB; ++pb) {
           acc[fb][pb][4 * q] += bv.x; acc[fb][pb][4 * q + 1] += bv.y;
@@ -142,12 +192,12 @@ struct EpiGnSilu {
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < RPG; ++j) { const int L = g * RPG + j; s += acc[L / 16][pb][L % 16]; }
-        if (GW >= 8) s += __shfl_xor(s, 32);
+        if (GW >= 8) s += swap_halves(s);
         const float m = s * (1.0f / GW);
         float qs = 0.f;
 #pragma unroll
         for (int j = 0; j < RPG; ++j) { const int L = g * RPG + j; const float d = acc[L / 16][pb][L % 16] - m; qs = fmaf(d, d, qs); }
-        if (GW >= 8) qs += __shfl_xor(qs, 32);
+        if (GW >= 8) qs += swap_halves(qs);
         mean[g] = m;
         rstd[g] = 1.0f / sqrtf(qs * (1.0f / GW) + GN_EPS);
       }
@@ -158,7 +208,7 @@ struct EpiGnSilu {
         for (int q = 0; q < 4; ++q) {
           const int f = fw + 32 * fb + 8 * q + 4 * h;
           const int g = (fb * 16 + 4 * q) / RPG;
-          const float4 gv = ldq<FAST>(a.gamma, f, F), bev = ldq<FAST>(a.beta, f, F);
+          const float4 gv = pre.gamma[fb][q], bev = pre.beta[fb][q];
           const float4 z = make_float4(acc[fb][pb][4 * q], acc[fb][pb][4 * q + 1], acc[fb][pb][4 * q + 2], acc[fb][pb][4 * q + 3]);
           if (a.z_out && prow) {
             stq<FAST>(a.z_out + (size_t)p * a.ldz, f, F, z);
@@ -198,6 +248,7 @@ struct EpiGnSilu {
 // (osd_set_schedule), which replaces three IEEE divides per element by two FMAs; the result
 // differs from the reference's op order by a few ulp of the same intermediate magnitudes.
 struct EpiPosterior {
+  static constexpr bool COUNTED_STORES = true;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias;
@@ -214,8 +265,19 @@ struct EpiPosterior {
     return F % 4 == 0 && al16(a.bias) && al16(a.xin) && al16(a.xout) && a.ldx % 4 == 0 && a.ldo % 4 == 0 &&
            (!a.z || (al16(a.z) && a.ldzz % 4 == 0 && a.z_step_stride % 4 == 0));
   }
+  template <int NFB> struct Pre { float4 bias[NFB][4]; };
+  template <int NFB, bool FAST>
+  static __device__ __forceinline__ Pre<NFB> prefetch(const Args& a, int fw, int lane, int F) {
+    Pre<NFB> r;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r.bias[fb][q] = ldq<FAST>(a.bias, fw + 32 * fb + 8 * q + 4 * h, F);
+    return r;
+  }
   template <int NFB, int NPB, bool FAST>
-  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, int fw, int pw, int lane, int F, int P) {
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P) {
     const int l31 = lane & 31, h = lane >> 5;
     const int t = a.t_dev ? *a.t_dev : a.t_imm;
     const float* c = a.coef + 4 * t;
@@ -226,7 +288,7 @@ struct EpiPosterior {
       const int p = pw + 32 * pb + l31;
       const int pc = p < P ? p : P - 1;
       const bool ok = p < P && f < F;
-      const float4 bv = ldq<FAST>(a.bias, f, F);
+      const float4 bv = pre.bias[fb][q];
       const float4 x = ldq<FAST>(a.xin + (size_t)pc * a.ldx, f, F);
       const float e[4] = {acc[fb][pb][4 * q] + bv.x, acc[fb][pb][4 * q + 1] + bv.y, acc[fb][pb][4 * q + 2] + bv.z, acc[fb][pb][4 * q + 3] + bv.w};
       const float xv[4] = {x.x, x.y, x.z, x.w};
@@ -253,6 +315,7 @@ struct EpiPosterior {
 // ---- output_proj fused with the MSE loss (models/diffusion.py:373-377) and its gradient ----
 // d = (acc + bias) - noise;  loss += sum d^2 * inv_count;  dout = d * gscale
 struct EpiMse {
+  static constexpr bool COUNTED_STORES = false;   // dout / pred are optional
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias; const float* noise; int ldn;
@@ -265,8 +328,19 @@ struct EpiMse {
     return F % 4 == 0 && al16(a.bias) && al16(a.noise) && a.ldn % 4 == 0 && (!a.dout || (al16(a.dout) && a.ldd % 4 == 0)) &&
            (!a.pred || (al16(a.pred) && a.ldp % 4 == 0));
   }
+  template <int NFB> struct Pre { float4 bias[NFB][4]; };
+  template <int NFB, bool FAST>
+  static __device__ __forceinline__ Pre<NFB> prefetch(const Args& a, int fw, int lane, int F) {
+    Pre<NFB> r;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r.bias[fb][q] = ldq<FAST>(a.bias, fw + 32 * fb + 8 * q + 4 * h, F);
+    return r;
+  }
   template <int NFB, int NPB, bool FAST>
-  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, int fw, int pw, int lane, int F, int P) {
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P) {
     const int l31 = lane & 31, h = lane >> 5;
     float part = 0.f;
     OSD_FOR_QUADS(fb, pb, q) {
@@ -274,7 +348,7 @@ struct EpiMse {
       const int p = pw + 32 * pb + l31;
       const int pc = p < P ? p : P - 1;
       const bool prow = p < P;
-      const float4 bv = ldq<FAST>(a.bias, f, F);
+      const float4 bv = pre.bias[fb][q];
       const float4 nz = ldq<FAST>(a.noise + (size_t)pc * a.ldn, f, F);
       const float4 e = make_float4(acc[fb][pb][4 * q] + bv.x, acc[fb][pb][4 * q + 1] + bv.y, acc[fb][pb][4 * q + 2] + bv.z, acc[fb][pb][4 * q + 3] + bv.w);
       if (a.pred && prow) stq<FAST>(a.pred + (size_t)p * a.ldp, f, F, e);
@@ -295,11 +369,23 @@ struct EpiMse {
 // ---- RBF-kernel sum for the MMD metric (utils/validation.py:287-296) -------------------------------
 // acc = x_f . y_p;  d2 = |x_f|^2 + |y_p|^2 - 2 acc;  sum += exp(-gamma * max(d2, 0)) over the valid tile
 struct EpiRbfSum {
+  static constexpr bool COUNTED_STORES = false;   // stores nothing
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args { const float* sqa; const float* sqb; float gamma; double* sum; };
   static bool fast_ok(const Args& a, int F) { return F % 4 == 0 && al16(a.sqa); }
+  template <int NFB> struct Pre { float4 sqa[NFB][4]; };
+  template <int NFB, bool FAST>
+  static __device__ __forceinline__ Pre<NFB> prefetch(const Args& a, int fw, int lane, int F) {
+    Pre<NFB> r;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r.sqa[fb][q] = ldq<FAST>(a.sqa, fw + 32 * fb + 8 * q + 4 * h, F);
+    return r;
+  }
   template <int NFB, int NPB, bool FAST>
-  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, int fw, int pw, int lane, int F, int P) {
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P) {
     const int l31 = lane & 31, h = lane >> 5;
     float part = 0.f;
 #pragma unroll
@@ -311,7 +397,7 @@ struct EpiRbfSum {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int f = fw + 32 * fb + 8 * q + 4 * h;
-          const float4 sa = ldq<FAST>(a.sqa, f, F);
+          const float4 sa = pre.sqa[fb][q];
           const float sav[4] = {sa.x, sa.y, sa.z, sa.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {

@@ -37,6 +37,8 @@ struct GemmArgs {
   int K0;
   int F, P, K;
   int kchunk;                  // gemm_kernel split-K: blockIdx.y reduces k in [y*kchunk, (y+1)*kchunk); 0 = no split
+  int persist;                 // gemm_glds_kernel: persistent patient-tile walk (see gemm_glds.h)
+  unsigned long long* stamps;  // diagnostic: per-wave s_memtime stamps [wave][4] (null in production)
   int stagger;                 // gemm_glds_kernel: start delay (units of 64 cycles) of the second co-resident workgroup
 };
 
@@ -301,7 +303,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g, typename 
     __syncthreads();
   }
 
-  Epi::template apply<T::NFB, T::NPB, FAST>(acc, ea, f0 + wf, p0 + wp, lane, g.F, g.P);
+  const auto pre = Epi::template prefetch<T::NFB, FAST>(ea, f0 + wf, lane, g.F);
+  Epi::template apply<T::NFB, T::NPB, FAST>(acc, ea, pre, f0 + wf, p0 + wp, lane, g.F, g.P);
 }
 
 // element (fb, reg) of a lane's fragment is feature  f_wave + 32*fb + 8*(reg>>2) + 4*h + (reg&3)

@@ -51,6 +51,13 @@ struct GldsTile {
   static constexpr int NB = T::BP / 32;
 };
 
+// Tile schedule.  g.persist == 0: one tile per workgroup, XCD-aware order (blocks b, b+8, ... share an
+// XCD and take the feature tiles of one patient tile).  g.persist == 1 (host guarantees 64 % nft == 0 and
+// gridDim.x % (8*nft) == 0): a workgroup keeps ONE feature tile and walks patient tiles
+// pt = pg, pg + gridDim.x/nft, ...; the nft workgroups of a patient group sit on one XCD.  Persistence
+// lets a workgroup (a) fetch its per-feature epilogue parameters once, before the first K loop,
+// (b) issue the first DMA of the NEXT tile before the epilogue of the current one, and (c) leave the
+// epilogue's stores in flight instead of draining them before its slot is reused.
 template <class T, class Epi>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, typename Epi::Args ea) {
   typedef GldsTile<T> G;
@@ -65,57 +72,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
   const int b = blockIdx.x;
   const int idx = b >> 3;
   const int ft = idx % nft;
-  const int pt = (idx / nft) * 8 + (b & 7);
-  if (pt >= npt) return;
-  const int f0 = ft * T::BF, p0 = pt * T::BP;
-
-  // Two workgroups share a CU (one wave of each per SIMD) and, launched together, run in lock
-  // step: both are in their VALU-only epilogue at the same time and the matrix pipe idles.  The
-  // workgroup that landed in hardware wave slot 1 of the first round therefore starts half a
-  // tile late; later rounds inherit the phase shift because slots then free up alternately.
-  // (Speed only: HW_REG_HW_ID wave-slot parity, measured placement b / b+256 per CU.)
-  if (g.stagger > 0 && b < 512 && (__builtin_amdgcn_s_getreg(0xF804) & 1u)) {
-    for (int i = 0; i < g.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
+  int pt, pstride;
+  if (g.persist) {
+    const int per_xcd = gridDim.x >> 3;
+    pt = idx / nft + (per_xcd / nft) * (b & 7);
+    pstride = gridDim.x / nft;
+  } else {
+    pt = (idx / nft) * 8 + (b & 7);
+    pstride = npt;                       // exactly one tile
   }
+  if (pt >= npt) return;
+  const int f0 = ft * T::BF;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned long long st0 = 0, st1 = 0, st2 = 0;
+  if (g.stamps) st0 = __builtin_amdgcn_s_memtime();
   const int wf = (wave / T::NWP) * T::WF;
   const int wp = (wave % T::NWP) * T::WP;
   const int l31 = lane & 31, h = lane >> 5;
 
-  f32x16 acc[T::NFB][T::NPB];
-#pragma unroll
-  for (int i = 0; i < T::NFB; ++i)
-#pragma unroll
-    for (int j = 0; j < T::NPB; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // per-feature epilogue parameters: in flight during the first K loop
+  const auto pre = Epi::template prefetch<T::NFB, true>(ea, f0 + wf, lane, g.F);
 
   // ---- staging addresses: wave-instruction (j*4 + wave) moves rows 8*(j*4+wave) .. +7 ----
-  int a_off[G::NA], a_k4[G::NA];
+  int a_off[G::NA];
+  int b_k4[G::NB], b_lrow[G::NB];
 #pragma unroll
   for (int j = 0; j < G::NA; ++j) {
     const int row = (j * 4 + wave) * 8 + (lane >> 3);
     int rg = f0 + row;
     rg = rg < g.F ? rg : g.F - 1;
-    a_k4[j] = 4 * ((lane & 7) ^ ((row >> 1) & 7));
-    a_off[j] = rg * g.lda + a_k4[j];
+    a_off[j] = rg * g.lda + 4 * ((lane & 7) ^ ((row >> 1) & 7));
   }
-  int b_row[G::NB], b_k4[G::NB];
 #pragma unroll
   for (int j = 0; j < G::NB; ++j) {
     const int row = (j * 4 + wave) * 8 + (lane >> 3);
-    int rg = p0 + row;
-    b_row[j] = rg < g.P ? rg : g.P - 1;
+    b_lrow[j] = row;
     b_k4[j] = 4 * ((lane & 7) ^ ((row >> 1) & 7));
   }
-  // ---- DMA of one tile, split into single wave-instructions so that each can be issued in the
-  // shadow of the MFMAs of the tile being computed (one LDS-DMA costs the wave ~60 issue cycles;
-  // eight of them in a row leave the matrix pipe idle, one between two groups of MFMAs is free).
-  struct StageCtx { unsigned la, lb; const float* bbase; int bld, bk, bkend, ak; };
-  auto stage_begin = [&](int k0, float* As, float* Bs) {
+  // ---- DMA of one K tile, split into single wave-instructions so that each can be issued between
+  // groups of MFMAs of the tile being computed.
+  struct StageCtx { unsigned la, lb; const float* bbase; int bld, bk, bkend, ak, p0; };
+  auto stage_begin = [&](int k0, int p0, float* As, float* Bs) {
     StageCtx c;
     c.la = __builtin_amdgcn_readfirstlane(lds_addr(As) + (unsigned)wave * 1024u);
     c.lb = __builtin_amdgcn_readfirstlane(lds_addr(Bs) + (unsigned)wave * 1024u);
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
     c.bk = first ? k0 : k0 - g.K0;
     c.bkend = first ? (g.K0 < g.K ? g.K0 : g.K) : g.K - g.K0;
     c.ak = k0;
+    c.p0 = p0;
     return c;
   };
   // piece j in [0, NA + NB): A pieces first
@@ -135,7 +136,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
       const int jb = j - G::NA;
       int k = c.bk + b_k4[jb];
       k = k < c.bkend - 4 ? k : c.bkend - 4;
-      glds16(c.bbase + (size_t)b_row[jb] * c.bld + k, __builtin_amdgcn_readfirstlane(c.lb + (unsigned)jb * 4096u));
+      int rg = c.p0 + b_lrow[jb];
+      rg = rg < g.P ? rg : g.P - 1;
+      glds16(c.bbase + (size_t)rg * c.bld + k, __builtin_amdgcn_readfirstlane(c.lb + (unsigned)jb * 4096u));
     }
   };
   constexpr int NPIECE = G::NA + G::NB;
@@ -147,7 +150,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
 #pragma unroll
   for (int pb = 0; pb < T::NPB; ++pb) { const int R = wp + 32 * pb + l31; b_rd[pb] = R * BK; b_sw[pb] = h ^ ((R >> 1) & 7); }
 
-  // quarter i of a staged tile; DO_STAGE: also issue DMA pieces [p0, p0 + 2*...) one per k-pair
+  f32x16 acc[T::NFB][T::NPB];
+
+  // quarter i of a staged tile; with do_stage one DMA piece of the next K tile follows each k-pair group
   auto compute = [&](const float* As, const float* Bs, int i, const StageCtx& sc, bool do_stage) {
     float a[T::NFB][4], bb[T::NPB][4];
 #pragma unroll
@@ -167,7 +172,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
 #pragma unroll
         for (int pb = 0; pb < T::NPB; ++pb)
           acc[fb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fb][e], bb[pb][e], acc[fb][pb], 0, 0, 0);
-      // one DMA piece behind each of the first pieces-per-quarter k-pairs of this quarter
       constexpr int PPQ = (NPIECE + 3) / 4;
       if (do_stage && e < PPQ && i * PPQ + e < NPIECE) {
         __builtin_amdgcn_sched_barrier(0);
@@ -178,28 +182,68 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
   };
 
   const int nk = (g.K + BK - 1) / BK;
+  // first K tile of the first patient tile
   {
-    const StageCtx c0 = stage_begin(0, As0, Bs0);
+    const StageCtx c0 = stage_begin(0, pt * T::BP, As0, Bs0);
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) stage_piece(c0, j);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the asm DMAs are invisible to hipcc's counters
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    float* Ac = (kt & 1) ? As1 : As0;
-    float* Bc = (kt & 1) ? Bs1 : Bs0;
-    const bool more = kt + 1 < nk;
-    const StageCtx sc = stage_begin(more ? (kt + 1) * BK : 0, (kt & 1) ? As0 : As1, (kt & 1) ? Bs0 : Bs1);
-    compute(Ac, Bc, 0, sc, more);
-    compute(Ac, Bc, 1, sc, more);
-    compute(Ac, Bc, 2, sc, more);
-    compute(Ac, Bc, 3, sc, more);
-    // the DMA of tile kt+1 had the MFMA block to land; publish it
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // stores of a FULL tile's epilogue: a lower bound on the vector-memory operations a wave issues after
+  // the prefetch DMA of the next tile, so vmcnt(that many) proves the (older) DMA has landed while the
+  // stores stay in flight.  Edge tiles may skip stores under an empty exec mask: they wait for vmcnt(0).
+  constexpr int FULL_TILE_STORES = T::NFB * T::NPB * 4;
+  bool counted_wait = false;
+  for (; pt < npt; pt += pstride) {
+    const int p0 = pt * T::BP;
+    if (counted_wait) {
+      if constexpr (FULL_TILE_STORES == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if constexpr (FULL_TILE_STORES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (FULL_TILE_STORES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the asm DMAs are invisible to hipcc's counters
+    }
     __syncthreads();
+    if (g.stamps && st1 == 0) st1 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int i = 0; i < T::NFB; ++i)
+#pragma unroll
+      for (int j = 0; j < T::NPB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt) {
+      float* Ac = (kt & 1) ? As1 : As0;
+      float* Bc = (kt & 1) ? Bs1 : Bs0;
+      const bool more = kt + 1 < nk;
+      const StageCtx sc = stage_begin(more ? (kt + 1) * BK : 0, p0, (kt & 1) ? As0 : As1, (kt & 1) ? Bs0 : Bs1);
+      compute(Ac, Bc, 0, sc, more);
+      compute(Ac, Bc, 1, sc, more);
+      compute(Ac, Bc, 2, sc, more);
+      compute(Ac, Bc, 3, sc, more);
+      // the DMA of K tile kt+1 had the MFMA block to land; publish it
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (g.stamps && st2 == 0) st2 = __builtin_amdgcn_s_memtime();
+    // first K tile of the next patient tile: every wave has left the K loop through its last barrier,
+    // so buffer 0 is free; the DMA flies while the epilogue runs
+    const int ptn = pt + pstride;
+    if (ptn < npt) {
+      const StageCtx cn = stage_begin(0, ptn * T::BP, As0, Bs0);
+#pragma unroll
+      for (int j = 0; j < NPIECE; ++j) stage_piece(cn, j);
+    }
+    counted_wait = Epi::COUNTED_STORES && (p0 + T::BP <= g.P) && (f0 + T::BF <= g.F);
+    Epi::template apply<T::NFB, T::NPB, true>(acc, ea, pre, f0 + wf, p0 + wp, lane, g.F, g.P);
   }
-
-  Epi::template apply<T::NFB, T::NPB, true>(acc, ea, f0 + wf, p0 + wp, lane, g.F, g.P);
+  if (g.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // include the store drain in the last interval
+    const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+      unsigned long long* o = g.stamps + ((size_t)blockIdx.x * 4 + wave) * 4;
+      o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+    }
+  }
 }
 
 }  // namespace osd

