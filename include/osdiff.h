@@ -188,6 +188,41 @@ int osd_val_mean_offdiag_corr(void *stream, int device, const float *data, int64
 int osd_val_pearson(void *stream, int device, const float *a, int lda, const float *b, int ldb,
                     int64_t rows, double *out);
 
+/* ---- biological constraint losses (north_star) ------------------------------
+ * The reference declares them at models/cvae.py:262-302 as stubs that return 0.0 (and the diffusion
+ * model has none), so nothing is added unless osd_set_constraints() configures them:
+ *   pathway coherence    L_pc = mean_P (1 - c_P), c_P = mean off-diagonal Pearson correlation over the
+ *                        batch rows of the member columns of pathway P (utils/validation.py:144-173);
+ *                        pathways with fewer than 2 members are skipped
+ *   mutation-expression  L_me = mean_{i in A, j in B} (corr_recon(i,j) - corr_true(i,j))^2
+ *                        ("MSE on correlation matrices", models/cvae.py:296-297), |A|, |B| <= 64
+ * Columns are indices into the D-wide feature vector; constant columns count as correlation 0. */
+typedef struct osd_constraints {
+  const int32_t *pathway_offsets;   /* host int32[n_pathways + 1], CSR over pathway_members */
+  const int32_t *pathway_members;   /* host int32[offsets[n_pathways]] */
+  int32_t n_pathways;               /* 0 disables the pathway term */
+  double pathway_weight;            /* config.yaml:58 pathway_coherence_weight */
+  const int32_t *cols_a;            /* host int32[n_a], e.g. mutation columns */
+  const int32_t *cols_b;            /* host int32[n_b], e.g. pathway-score or expression columns */
+  int32_t n_a, n_b;                 /* 0 disables the mutation-expression term */
+  double mutexpr_weight;            /* config.yaml:59 mutation_expression_weight */
+} osd_constraints;
+/* Configures (c == NULL: clears) the terms osd_train_loss_fwd_bwd adds to the eps-MSE, evaluated on
+ * x0_hat = (x_t - sqrt(1-ac_t) eps_hat) / sqrt(ac_t) (models/diffusion.py:405) against x0 of the batch:
+ * loss = mse + pathway_weight * L_pc + mutexpr_weight * L_me, gradients flow into eps_hat. */
+int osd_set_constraints(osd_handle *h, const osd_constraints *c);
+/* (mse, L_pc, L_me) of the last osd_train_loss_fwd_bwd call; synchronises the handle's stream. */
+int osd_get_loss_parts(osd_handle *h, float *parts_host3);
+/* Stand-alone ops (stream/device based, synchronous): loss_out (dev float[1]) += weight * L and, when
+ * dx != NULL, dx (dev [rows][ld]) += weight * dL/dx.  x, x_recon, x_true: dev [rows][ld], cols <= ld. */
+int osd_loss_pathway_coherence(void *stream, int device, const float *x, int64_t rows, int ld, int cols,
+                               const int32_t *offsets_host, const int32_t *members_host, int n_pathways,
+                               double weight, float *loss_out, float *dx);
+int osd_loss_mutation_expression(void *stream, int device, const float *x_recon, const float *x_true,
+                                 int64_t rows, int ld, int cols, const int32_t *cols_a_host, int n_a,
+                                 const int32_t *cols_b_host, int n_b, double weight, float *loss_out,
+                                 float *dx);
+
 /* ---- building blocks, exported for the parity tests ------------------------ */
 /* y[n][N] = act(x[n][K] @ w[N][K]^T + b), act = identity (silu=0) or SiLU. */
 int osd_op_linear(osd_handle *h, const float *x, const float *w, const float *b, int64_t n, int K,

@@ -25,6 +25,15 @@ class OsdConfig(C.Structure):
     ]
 
 
+class OsdConstraints(C.Structure):
+    _fields_ = [
+        ("pathway_offsets", C.POINTER(C.c_int32)), ("pathway_members", C.POINTER(C.c_int32)), ("n_pathways", C.c_int32),
+        ("pathway_weight", C.c_double),
+        ("cols_a", C.POINTER(C.c_int32)), ("cols_b", C.POINTER(C.c_int32)), ("n_a", C.c_int32), ("n_b", C.c_int32),
+        ("mutexpr_weight", C.c_double),
+    ]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     "osd_version": (C.c_int, []),
@@ -51,6 +60,12 @@ _SIGNATURES = {
     "osd_val_ks_extremes": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "osd_val_mean_offdiag_corr": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
     "osd_val_pearson": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int64, C.POINTER(C.c_double)]),
+    "osd_set_constraints": (C.c_int, [_P, C.POINTER(OsdConstraints)]),
+    "osd_get_loss_parts": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "osd_loss_pathway_coherence": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int,
+                                             C.c_double, _P, _P]),
+    "osd_loss_mutation_expression": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int,
+                                               C.POINTER(C.c_int32), C.c_int, C.c_double, _P, _P]),
     "osd_profile_step": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
     "osd_op_linear": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     "osd_op_linear_gn_silu": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int, _P]),

@@ -322,6 +322,8 @@ int osd_destroy(osd_handle* h) {
   float* bufs[] = {h->w_in_packed, h->d_sqrt_ac, h->d_sqrt_1m, h->d_coef, h->d_time_emb, h->d_temb, h->train_arena, h->loss_dev};
   for (float* p : bufs) if (p) e = hipFree(p);
   if (h->normsq_dev) e = hipFree(h->normsq_dev);
+  if (h->parts_dev) e = hipFree(h->parts_dev);
+  cons_free_plan(&h->cons);
   if (h->fork_ev) e = hipEventDestroy(h->fork_ev);
   (void)e;
   delete h;

@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include "../../include/osdiff.h"
+#include "constraints.h"
 
 namespace osd {
 
@@ -101,6 +102,10 @@ struct osd_handle {
   int64_t train_arena_floats = 0;
   float* loss_dev = nullptr;
   double* normsq_dev = nullptr;
+  // constraint losses (osd_set_constraints); parts_dev = (mse, L_pc, L_me) of the last training call
+  osd::ConsPlan cons;
+  double w_pathway = 0.0, w_mutexpr = 0.0;
+  float* parts_dev = nullptr;
   // osd_profile_step: when non-null, run_trunk records prof_events[prof_i++] after every launch
   std::vector<hipEvent_t>* prof_events = nullptr;
   int prof_i = 0;

@@ -22,9 +22,12 @@ struct TrainWs {
   float* partials;   // gn backward column partials
   float* slabs;      // split-K wgrad partial tiles
   int64_t slab_floats;
+  // constraint losses (only carved when configured)
+  float *pred, *g_x0;
+  ConsWs cw;
 };
 
-static int64_t carve_train(const Arch& a, float* base, int64_t n, TrainWs* w) {
+static int64_t carve_train(const Arch& a, float* base, int64_t n, const ConsPlan* cp, TrainWs* w) {
   int64_t off = 0;
   auto take = [&](int64_t floats) { float* p = base ? base + off : nullptr; off += align_up64(floats); return p; };
   float* fbase = base;
@@ -46,6 +49,13 @@ static int64_t carve_train(const Arch& a, float* base, int64_t n, TrainWs* w) {
   w->partials = take((int64_t)GN_BWD_MAX_BLOCKS * 3 * cmax);
   w->slab_floats = 16 * 1024 * 1024;      // 64 MB of split-K slabs
   w->slabs = take(w->slab_floats);
+  w->pred = w->g_x0 = nullptr;
+  if (cp) {
+    w->pred = take(n * a.D); w->g_x0 = take(n * a.D);
+    const int64_t bytes = cons_carve(*cp, n, a.D, nullptr, &w->cw);
+    char* cbase = (char*)take((bytes + 3) / 4);
+    cons_carve(*cp, n, a.D, cbase, &w->cw);
+  }
   return off;
 }
 
@@ -119,8 +129,13 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   const int D = a.D;
   const uint32_t roff = (uint32_t)row_offset;
 
+  const bool use_pw = h->cons.n_pathways > 0 && h->w_pathway != 0.0;
+  const bool use_me = h->cons.n_a > 0 && h->w_mutexpr != 0.0;
+  const ConsPlan* cp = (use_pw || use_me) ? &h->cons : nullptr;
+  if (cp && n < 2) { set_error("the constraint losses need at least 2 rows"); return OSD_EINVAL; }
+  if (!h->parts_dev) OSD_HIP(hipMalloc((void**)&h->parts_dev, 64));
   TrainWs w;
-  const int64_t need = carve_train(a, nullptr, n, &w);
+  const int64_t need = carve_train(a, nullptr, n, cp, &w);
   if (h->train_arena_floats < need) {
     if (h->train_arena) { OSD_HIP(hipStreamSynchronize(s)); OSD_HIP(hipFree(h->train_arena)); h->train_arena = nullptr; h->train_arena_floats = 0; }
     void* p = nullptr;
@@ -128,13 +143,15 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
     h->train_arena = (float*)p;
     h->train_arena_floats = need;
   }
-  carve_train(a, h->train_arena, n, &w);
+  carve_train(a, h->train_arena, n, cp, &w);
 
   // ---- zero everything that is accumulated atomically ----
   {
     ZeroList zl{};
     auto add = [&](float* p, int64_t c) { zl.ptr[zl.n] = p; zl.count[zl.n] = c; ++zl.n; };
     add(loss_out, 1);
+    if (cp) add(h->parts_dev, 3);
+    if (cp && grads) add(w.g_x0, n * (int64_t)D);
     if (grads) {
       add(w.g_temb, (int64_t)a.T * a.H0);
       const int small[] = {pm.ce0_b, pm.ce2_b, pm.in_b, pm.cp_b, pm.tp_b, pm.out_b};
@@ -173,10 +190,25 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
     GemmArgs g = output_proj_args(h, W.f, n);
     EpiMse::Args ea{};
     ea.bias = h->params[pm.out_b]; ea.noise = eps_true; ea.ldn = D;
-    ea.dout = grads ? W.d_out : nullptr; ea.ldd = D; ea.pred = nullptr; ea.ldp = D; ea.loss = loss_out;
+    ea.dout = grads ? W.d_out : nullptr; ea.ldd = D; ea.pred = cp ? W.pred : nullptr; ea.ldp = D; ea.loss = loss_out;
     ea.inv_count = (float)(1.0 / ((double)n * (double)D));
     ea.gscale = (float)(2.0 * (double)loss_scale / ((double)n * (double)D));
     OSD_HIP(launch_mse(s, g, ea));
+  }
+  if (cp) {
+    OSD_HIP(hipMemcpyAsync(h->parts_dev, loss_out, 4, hipMemcpyDeviceToDevice, s));
+    // constraint terms on x0_hat (models/diffusion.py:405) against the batch's x0; their gradient joins dL/d eps_hat
+    OSD_HIP(launch_x0hat(s, W.x_t, t_idx, h->d_sqrt_ac, h->d_sqrt_1m, n, D, W.pred));
+    OSD_HIP(hipMemsetAsync(W.cw.acc, 0, (size_t)W.cw.acc_doubles * 8, s));
+    OSD_HIP(cons_moments(s, W.pred, D, n, D, W.cw.acc, W.cw.mi_r));
+    float* gx = grads ? W.g_x0 : nullptr;
+    if (use_pw)
+      OSD_HIP(cons_pathway(s, *cp, W.cw, W.pred, D, n, D, (float)h->w_pathway, (float)(h->w_pathway * loss_scale), loss_out, h->parts_dev + 1, gx));
+    if (use_me) {
+      OSD_HIP(cons_moments(s, x0, D, n, D, W.cw.acc + 2 * (int64_t)D, W.cw.mi_t));
+      OSD_HIP(cons_mutexpr(s, *cp, W.cw, W.pred, x0, D, n, D, (float)h->w_mutexpr, (float)(h->w_mutexpr * loss_scale), loss_out, h->parts_dev + 2, gx));
+    }
+    if (grads) OSD_HIP(launch_x0hat_bwd(s, W.g_x0, t_idx, h->d_sqrt_ac, h->d_sqrt_1m, n, D, W.d_out));
   }
   if (!grads) return OSD_OK;
 
@@ -247,6 +279,31 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   OSD_HIP(launch_colsum(s, W.g_u, 64, n, 64, grads[pm.ce0_b]));
   OSD_TRY(record());
   if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
+  return OSD_OK;
+}
+
+int osd_set_constraints(osd_handle* h, const osd_constraints* c) {
+  if (!h) { set_error("null handle"); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  if (h->stream) OSD_HIP(hipStreamSynchronize(h->stream));
+  ConsPlan fresh;
+  if (c) {
+    if (c->pathway_weight < 0 || c->mutexpr_weight < 0) { set_error("constraint weights must be >= 0"); return OSD_EINVAL; }
+    OSD_TRY(cons_build_plan(c->pathway_offsets, c->pathway_members, c->n_pathways, c->cols_a, c->n_a, c->cols_b, c->n_b, h->arch.D, &fresh));
+  }
+  cons_free_plan(&h->cons);
+  h->cons = fresh;
+  h->w_pathway = c ? c->pathway_weight : 0.0;
+  h->w_mutexpr = c ? c->mutexpr_weight : 0.0;
+  return OSD_OK;
+}
+
+int osd_get_loss_parts(osd_handle* h, float* parts_host3) {
+  if (!h || !parts_host3) { set_error("null argument"); return OSD_EINVAL; }
+  if (!h->parts_dev || !(h->cons.n_pathways > 0 || h->cons.n_a > 0)) { set_error("no constraint losses are configured on this handle"); return OSD_ESTATE; }
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  OSD_HIP(hipMemcpyAsync(parts_host3, h->parts_dev, 12, hipMemcpyDeviceToHost, h->stream));
+  OSD_HIP(hipStreamSynchronize(h->stream));
   return OSD_OK;
 }
 

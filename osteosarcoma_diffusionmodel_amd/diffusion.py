@@ -144,6 +144,24 @@ class _Engine:
         s1 = model.sqrt_one_minus_alphas_cumprod.detach().float().cpu().contiguous()
         L.check(lib.osd_set_schedule(self.handle, L.ptr(sa), L.ptr(s1), L.ptr(coef.contiguous()), L.ptr(temb)))
         self._sig = None
+        self.constraints_version = 0
+
+    def set_constraints(self, spec):
+        lib = L.lib()
+        if spec is None:
+            L.check(lib.osd_set_constraints(self.handle, None))
+            return
+        from .constraints import csr_from_pathways
+        off, mem = csr_from_pathways(spec["pathways"])
+        ca = np.ascontiguousarray(spec["cols_a"], dtype=np.int32)
+        cb = np.ascontiguousarray(spec["cols_b"], dtype=np.int32)
+        c = L.OsdConstraints()
+        i32p = C.POINTER(C.c_int32)
+        c.pathway_offsets, c.pathway_members, c.n_pathways = off.ctypes.data_as(i32p), mem.ctypes.data_as(i32p), len(off) - 1
+        c.pathway_weight = spec["w_pc"]
+        c.cols_a, c.cols_b, c.n_a, c.n_b = ca.ctypes.data_as(i32p), cb.ctypes.data_as(i32p), len(ca), len(cb)
+        c.mutexpr_weight = spec["w_me"]
+        L.check(lib.osd_set_constraints(self.handle, C.byref(c)))
 
     def close(self):
         if self.handle:
@@ -210,6 +228,39 @@ class BiologyAwareDiffusionModel(nn.Module):
         self.sample_chunk_rows: Optional[int] = None
         self.sample_streams: Optional[int] = None
         self.use_graph: bool = True
+        # optional constraint losses (set_constraints); None = the reference's eps-MSE only
+        self._constraints = None
+        self._constraints_version = 0
+
+    # -- constraint losses (north_star; stubs at models/cvae.py:262-302) -----------------------------
+    def set_constraints(self, pathways=None, mutation_columns=None, target_columns=None, *, pathway_weight: Optional[float] = None,
+                        mutexpr_weight: Optional[float] = None, config: Optional[dict] = None):
+        """Add the pathway-coherence and/or mutation-expression terms to the training loss (``forward``).
+
+        pathways: list of member-column lists (columns of the D-wide feature vector; see
+        ``constraints.pathways_from_matrix``); mutation_columns / target_columns: the two column sets of the
+        correlation block (at most 64 each).  Weights default to ``config['model']['constraints']``
+        (config.yaml:57-60) when a config is given, else 1.0.  Call with no arguments to clear."""
+        cons = (config or {}).get("model", {}).get("constraints", {})
+        if pathways is None and mutation_columns is None:
+            self._constraints = None
+        else:
+            if (mutation_columns is None) != (target_columns is None):
+                raise ValueError("mutation_columns and target_columns go together")
+            self._constraints = {
+                "pathways": [list(map(int, p)) for p in (pathways or [])],
+                "cols_a": list(map(int, mutation_columns or [])), "cols_b": list(map(int, target_columns or [])),
+                "w_pc": float(pathway_weight if pathway_weight is not None else cons.get("pathway_coherence_weight", 1.0)),
+                "w_me": float(mutexpr_weight if mutexpr_weight is not None else cons.get("mutation_expression_weight", 1.0)),
+            }
+        self._constraints_version += 1
+
+    def last_loss_parts(self):
+        """(mse, L_pc, L_me) of the most recent training ``forward`` with constraints configured."""
+        eng = self._engine()
+        out = (C.c_float * 3)()
+        L.check(L.lib().osd_get_loss_parts(eng.handle, out))
+        return float(out[0]), float(out[1]), float(out[2])
 
     # -- schedule: same torch expressions as models/diffusion.py:312-326, hence bit-identical buffers
     def _get_beta_schedule(self, schedule_type: str, num_steps: int):
@@ -259,6 +310,9 @@ class BiologyAwareDiffusionModel(nn.Module):
                 eng = _Engine(self, torch.device("cuda", key[1]))
             self._engines[key] = eng
         eng.sync(self)
+        if eng.constraints_version != self._constraints_version:
+            eng.set_constraints(self._constraints)
+            eng.constraints_version = self._constraints_version
         if self.sample_chunk_rows:
             L.check(L.lib().osd_set_option(eng.handle, b"chunk_rows", int(self.sample_chunk_rows)))
         if self.sample_streams:
