@@ -323,6 +323,8 @@ int osd_destroy(osd_handle* h) {
   for (float* p : bufs) if (p) e = hipFree(p);
   if (h->normsq_dev) e = hipFree(h->normsq_dev);
   if (h->parts_dev) e = hipFree(h->parts_dev);
+  for (hipEvent_t ev : h->ev_pool) e = hipEventDestroy(ev);
+  if (h->wgrad_stream) e = hipStreamDestroy(h->wgrad_stream);
   cons_free_plan(&h->cons);
   if (h->fork_ev) e = hipEventDestroy(h->fork_ev);
   (void)e;
@@ -346,6 +348,11 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "n_streams")) {
     if (value < 1 || value > 8) { set_error("n_streams must be in [1,8]"); return OSD_EINVAL; }
     h->n_streams = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "train_streams")) {
+    if (value < 1 || value > 2) { set_error("train_streams must be 1 or 2"); return OSD_EINVAL; }
+    h->two_stream_bwd = value == 2;
     return OSD_OK;
   }
   set_error("unknown option '%s'", name);

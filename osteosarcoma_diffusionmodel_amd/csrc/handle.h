@@ -102,6 +102,10 @@ struct osd_handle {
   int64_t train_arena_floats = 0;
   float* loss_dev = nullptr;
   double* normsq_dev = nullptr;
+  // weight-gradient side stream of the backward pass and its fork/join events
+  hipStream_t wgrad_stream = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  int two_stream_bwd = 1;            // osd_set_option("train_streams", 1|2)
   // constraint losses (osd_set_constraints); parts_dev = (mse, L_pc, L_me) of the last training call
   osd::ConsPlan cons;
   double w_pathway = 0.0, w_mutexpr = 0.0;

@@ -213,15 +213,47 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   if (!grads) return OSD_OK;
 
   // ---- backward ----
+  // Two streams: the chain  GroupNorm/SiLU backward -> dgrad -> next layer  is the critical path and stays on the
+  // handle's stream; every weight/bias gradient (wgrad, split-K slab sums, column sums) is a leaf and goes to a
+  // lower-priority side stream that fills the CUs the small dgrad launches leave idle.  fork() orders the side
+  // stream behind what the main stream has produced so far; the side stream owns the slab workspace.
+  hipStream_t s2 = s;
+  if (h->two_stream_bwd) {
+    if (!h->wgrad_stream) {
+      int lo = 0, hi = 0;
+      OSD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      OSD_HIP(hipStreamCreateWithPriority(&h->wgrad_stream, hipStreamNonBlocking, lo));
+    }
+    s2 = h->wgrad_stream;
+  }
+  size_t ev_used = 0;
+  auto next_event = [&](hipEvent_t* out) -> int {
+    if (ev_used == h->ev_pool.size()) {
+      hipEvent_t e;
+      OSD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->ev_pool.push_back(e);
+    }
+    *out = h->ev_pool[ev_used++];
+    return OSD_OK;
+  };
+  auto fork = [&]() -> int {          // side stream waits for everything enqueued on the main stream so far
+    if (s2 == s) return OSD_OK;
+    hipEvent_t e;
+    OSD_TRY(next_event(&e));
+    OSD_HIP(hipEventRecord(e, s));
+    OSD_HIP(hipStreamWaitEvent(s2, e, 0));
+    return OSD_OK;
+  };
   int ev = 0;
-  auto record = [&]() -> int {
-    if (events) OSD_HIP(hipEventRecord((hipEvent_t)events[ev], s));
+  auto record = [&]() -> int {        // bucket complete: its last writer is on the side stream
+    if (events) OSD_HIP(hipEventRecord((hipEvent_t)events[ev], s2));
     ++ev;
     return OSD_OK;
   };
   // output_proj
-  OSD_HIP(wgrad(s, W, W.f.out[last], Hl, Hl, W.d_out, D, D, n, grads[pm.out_w], Hl));
-  OSD_HIP(launch_colsum(s, W.d_out, D, n, D, grads[pm.out_b]));
+  OSD_TRY(fork());
+  OSD_HIP(wgrad(s2, W, W.f.out[last], Hl, Hl, W.d_out, D, D, n, grads[pm.out_w], Hl));
+  OSD_HIP(launch_colsum(s2, W.d_out, D, n, D, grads[pm.out_b]));
   OSD_TRY(record());
   OSD_HIP(dgrad(s, h->params[pm.out_w], Hl, Hl, W.d_out, D, D, n, W.g_out[last], Hl, false));
 
@@ -236,7 +268,8 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
     ga.gz = W.g_z2[b]; ga.dgamma = grads[l2.gamma]; ga.dbeta = grads[l2.beta]; ga.dbias = grads[l2.b];
     ga.rows = n; ga.C = C; ga.drop_mode = 0; ga.partials = W.partials;
     OSD_HIP(launch_gn_silu_bwd(s, l2.gw, ga));
-    OSD_HIP(wgrad(s, W, W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C));
+    OSD_TRY(fork());
+    OSD_HIP(wgrad(s2, W, W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C));
     OSD_HIP(dgrad(s, h->params[l2.w], C, C, W.g_z2[b], C, C, n, W.g_mid[b], C, false));
     // first half (dropout sits behind it)
     GnBwdArgs gb{};
@@ -247,13 +280,14 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
     gb.mask = (drop && masks) ? masks[b] : nullptr; gb.keep_scale = keep_scale; gb.p_drop = h->cfg.dropout_p;
     gb.seed = seed; gb.row_offset = roff; gb.step = 0; gb.tag = TAG_DROPOUT + (uint32_t)b;
     OSD_HIP(launch_gn_silu_bwd(s, l1.gw, gb));
+    OSD_TRY(fork());
     const int Kt = l1.K1 + l1.K2;
     const float* xin = (b == 0) ? W.f.h0 : W.f.out[b - 1];
-    OSD_HIP(wgrad(s, W, xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt));
+    OSD_HIP(wgrad(s2, W, xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt));
     int skip_block = -1;
     if (l1.K2 > 0) {
       skip_block = a.n_enc - 1 - (b - a.n_enc - 1);
-      OSD_HIP(wgrad(s, W, W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt));
+      OSD_HIP(wgrad(s2, W, W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt));
     }
     OSD_TRY(record());
     // dgrad into the producer of the main input; encoder outputs already hold their skip gradient
@@ -263,21 +297,30 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
     if (l1.K2 > 0) OSD_HIP(dgrad(s, h->params[l1.w] + l1.K1, Kt, l1.K2, W.g_z1[b], C, C, n, W.g_out[skip_block], l1.K2, false));
   }
   // input_proj, time_proj, cond_proj, ConditionalEmbedding  (h0 = x W^T + b + t_emb[t] + c_proj)
-  OSD_HIP(wgrad(s, W, W.x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D));
-  OSD_HIP(launch_colsum(s, W.g_h0, a.H0, n, a.H0, grads[pm.in_b]));
-  OSD_HIP(hipMemcpyAsync(grads[pm.cp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s));
-  OSD_HIP(hipMemcpyAsync(grads[pm.tp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s));
+  OSD_TRY(fork());
+  OSD_HIP(wgrad(s2, W, W.x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D));
+  OSD_HIP(wgrad(s2, W, W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64));
+  OSD_HIP(launch_colsum(s2, W.g_h0, a.H0, n, a.H0, grads[pm.in_b]));
+  OSD_HIP(hipMemcpyAsync(grads[pm.cp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s2));
+  OSD_HIP(hipMemcpyAsync(grads[pm.tp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s2));
   OSD_HIP(launch_scatter_rows(s, W.g_h0, t_idx, n, a.H0, W.g_temb));
-  OSD_HIP(wgrad(s, W, h->d_time_emb, a.time_dim, a.time_dim, W.g_temb, a.H0, a.H0, a.T, grads[pm.tp_w], a.time_dim));
-  OSD_HIP(wgrad(s, W, W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64));
   OSD_HIP(dgrad(s, h->params[pm.cp_w], 64, 64, W.g_h0, a.H0, a.H0, n, W.g_ce2, 64, false));
-  OSD_HIP(wgrad(s, W, W.f.ce1, 64, 64, W.g_ce2, 64, 64, n, grads[pm.ce2_w], 64));
-  OSD_HIP(launch_colsum(s, W.g_ce2, 64, n, 64, grads[pm.ce2_b]));
+  OSD_TRY(fork());
+  OSD_HIP(wgrad(s2, W, h->d_time_emb, a.time_dim, a.time_dim, W.g_temb, a.H0, a.H0, a.T, grads[pm.tp_w], a.time_dim));
+  OSD_HIP(wgrad(s2, W, W.f.ce1, 64, 64, W.g_ce2, 64, 64, n, grads[pm.ce2_w], 64));
+  OSD_HIP(launch_colsum(s2, W.g_ce2, 64, n, 64, grads[pm.ce2_b]));
   OSD_HIP(dgrad(s, h->params[pm.ce2_w], 64, 64, W.g_ce2, 64, 64, n, W.g_ce1, 64, false));
   OSD_HIP(launch_silu_bwd(s, W.u0, W.g_ce1, W.g_u, n * 64));
-  OSD_HIP(wgrad(s, W, cond, a.cond_dim, a.cond_dim, W.g_u, 64, 64, n, grads[pm.ce0_w], a.cond_dim));
-  OSD_HIP(launch_colsum(s, W.g_u, 64, n, 64, grads[pm.ce0_b]));
+  OSD_TRY(fork());
+  OSD_HIP(wgrad(s2, W, cond, a.cond_dim, a.cond_dim, W.g_u, 64, 64, n, grads[pm.ce0_w], a.cond_dim));
+  OSD_HIP(launch_colsum(s2, W.g_u, 64, n, 64, grads[pm.ce0_b]));
   OSD_TRY(record());
+  if (s2 != s) {                      // join: the caller's stream owns every result again
+    hipEvent_t e;
+    OSD_TRY(next_event(&e));
+    OSD_HIP(hipEventRecord(e, s2));
+    OSD_HIP(hipStreamWaitEvent(s, e, 0));
+  }
   if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
   return OSD_OK;
 }

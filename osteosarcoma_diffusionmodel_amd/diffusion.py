@@ -228,6 +228,7 @@ class BiologyAwareDiffusionModel(nn.Module):
         self.sample_chunk_rows: Optional[int] = None
         self.sample_streams: Optional[int] = None
         self.use_graph: bool = True
+        self.train_streams: Optional[int] = None      # 1 = whole backward on one stream, 2 (library default) = weight gradients on a side stream
         # optional constraint losses (set_constraints); None = the reference's eps-MSE only
         self._constraints = None
         self._constraints_version = 0
@@ -317,6 +318,8 @@ class BiologyAwareDiffusionModel(nn.Module):
             L.check(L.lib().osd_set_option(eng.handle, b"chunk_rows", int(self.sample_chunk_rows)))
         if self.sample_streams:
             L.check(L.lib().osd_set_option(eng.handle, b"n_streams", int(self.sample_streams)))
+        if self.train_streams:
+            L.check(L.lib().osd_set_option(eng.handle, b"train_streams", int(self.train_streams)))
         return eng
 
     def _prep(self, t: torch.Tensor, cols: Optional[int] = None, name: str = "tensor") -> torch.Tensor:

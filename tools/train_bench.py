@@ -19,6 +19,9 @@ conf["training"] = {"learning_rate": 1e-4, "weight_decay": 1e-5, "patience": 100
                     "save_frequency": 10, "val_split": 0.2, "random_seed": 42, "batch_size": B}
 torch.manual_seed(0)
 model = BiologyAwareDiffusionModel(50, 1900, 50, 3, conf)
+import os
+if os.environ.get("OSD_TRAIN_STREAMS"):
+    model.train_streams = int(os.environ["OSD_TRAIN_STREAMS"])
 tr = Trainer(model, [], [], conf, device="cuda")
 model.train()
 g = torch.Generator(device="cuda").manual_seed(42)
