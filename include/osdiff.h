@@ -162,6 +162,13 @@ int osd_clip_adamw_step(osd_handle *h, float *param, float *grad, float *exp_avg
                         int64_t numel, double lr, double beta1, double beta2, double eps,
                         double weight_decay, double max_norm, int64_t step, float *grad_norm_out);
 
+/* The same step without a model handle (any nn.Module's flat buffers, e.g. the cVAE): normsq_ws is
+ * caller-owned device scratch of 8 doubles. */
+int osd_nn_clip_adamw_step(void *stream, int device, double *normsq_ws, float *param, float *grad,
+                           float *exp_avg, float *exp_avg_sq, int64_t numel, double lr, double beta1,
+                           double beta2, double eps, double weight_decay, double max_norm, int64_t step,
+                           float *grad_norm_out);
+
 /* Measurement aid for bench.py: per-launch HIP-event timing of one reverse step on n rows
  * (eager launches on the handle's stream, averaged over reps after one warm-up pass).
  * Entry 0 = input_proj, 1..2*n_blocks = the Linear+GroupNorm+SiLU halves in execution order,
@@ -222,6 +229,53 @@ int osd_loss_mutation_expression(void *stream, int device, const float *x_recon,
                                  int64_t rows, int ld, int cols, const int32_t *cols_a_host, int n_a,
                                  const int32_t *cols_b_host, int n_b, double weight, float *loss_out,
                                  float *dx);
+
+/* ---- layer ops behind the cVAE mirror (models/cvae.py) -----------------------
+ * Stream/device based, asynchronous (nothing synchronises), every tensor a device pointer. */
+/* torch.cat([x1, x2], -1) -> nn.Linear (models/cvae.py:54-55, 97-98): y[n][N] = [x1|x2] w[N][K1+K2]^T + b.
+ * K2 == 0: plain Linear (x2 ignored). */
+int osd_nn_linear(void *stream, int device, const float *x1, int K1, const float *x2, int K2,
+                  const float *w, const float *b, int64_t n, int N, float *y);
+/* Its backward: dw[N][K1+K2] = gy^T [x1|x2] (overwritten), db[N] = column sums of gy (NULL: skipped),
+ * dx1[n][K1] = gy w[:, :K1] (NULL: skipped; the x2 panel -- the conditions -- gets no gradient). */
+int osd_nn_linear_bwd(void *stream, int device, const float *x1, int K1, const float *x2, int K2,
+                      const float *w, const float *gy, int64_t n, int N, float *dx1, float *dw, float *db);
+/* nn.BatchNorm1d -> nn.ReLU -> nn.Dropout (models/cvae.py:29-32, 79-82) on z[n][C].
+ *   training != 0: batch statistics (biased variance), running_mean/var updated with `momentum`
+ *                  (unbiased variance), dropout from `mask` (dev float 0/1 keep-mask [n][C]) or, when
+ *                  mask == NULL, Philox(seed, tag); n >= 2 required as in torch
+ *   training == 0: running statistics, no dropout
+ *   use_bn == 0:   ReLU -> Dropout only (the survival head, models/cvae.py:251-252)
+ * save_mean / save_invstd (dev float[C]) receive the statistics the backward needs. */
+int osd_nn_bn_relu_dropout(void *stream, int device, const float *z, int64_t n, int C, const float *gamma,
+                           const float *beta, float *running_mean, float *running_var, double momentum,
+                           double eps, int training, int use_bn, double p_drop, const float *mask,
+                           uint64_t seed, uint32_t tag, float *y, float *save_mean, float *save_invstd);
+int osd_nn_bn_relu_dropout_bwd(void *stream, int device, const float *gy, const float *z, int64_t n, int C,
+                               const float *gamma, const float *beta, const float *save_mean,
+                               const float *save_invstd, int training, int use_bn, double p_drop,
+                               const float *mask, uint64_t seed, uint32_t tag, float *dz, float *dgamma,
+                               float *dbeta);
+/* reparameterize (models/cvae.py:152-156): z = mu + eps * exp(0.5 * logvar); eps_in NULL -> Philox(seed)
+ * normals, written to eps_out when it is not NULL. */
+int osd_nn_reparameterize(void *stream, int device, const float *mu, const float *logvar, const float *eps_in,
+                          uint64_t seed, int64_t n, int Lz, float *z, float *eps_out);
+/* Backward of reparameterize: d_logvar = 0.5 * gz * (z - mu)   (d_mu is gz itself). */
+int osd_nn_reparameterize_bwd(void *stream, int device, const float *gz, const float *mu, const float *z,
+                              int64_t count, float *d_logvar);
+/* VAE loss (models/cvae.py:178-181): parts3 (dev float[3]) = (recon + kl, recon, kl) with
+ * recon = sum (x_recon - x)^2 / n, kl = -0.5 sum(1 + logvar - mu^2 - exp(logvar)) / n, and their
+ * gradients d_recon[n][D], d_mu[n][Lz], d_logvar[n][Lz] (each may be NULL). */
+int osd_nn_vae_loss(void *stream, int device, const float *x_recon, const float *x, const float *mu,
+                    const float *logvar, int64_t n, int D, int Lz, float *parts3, float *d_recon,
+                    float *d_mu, float *d_logvar);
+/* One tensor of MixupAugmentation.__call__ (utils/train.py:108-120) without a model handle:
+ * out[rows][cols] = lam * v + (1 - lam) * v[perm]. */
+int osd_nn_mixup(void *stream, int device, const float *v, const int64_t *perm, double lam, int64_t rows,
+                 int cols, float *out);
+/* F.mse_loss(a, b) over `count` elements (models/cvae.py:323): loss_out dev float[1], da (may be NULL). */
+int osd_nn_mse(void *stream, int device, const float *a, const float *b, int64_t count, float *loss_out,
+               float *da);
 
 /* ---- building blocks, exported for the parity tests ------------------------ */
 /* y[n][N] = act(x[n][K] @ w[N][K]^T + b), act = identity (silu=0) or SiLU. */

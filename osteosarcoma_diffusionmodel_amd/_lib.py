@@ -66,6 +66,19 @@ _SIGNATURES = {
                                              C.c_double, _P, _P]),
     "osd_loss_mutation_expression": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int,
                                                C.POINTER(C.c_int32), C.c_int, C.c_double, _P, _P]),
+    "osd_nn_linear": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int64, C.c_int, _P]),
+    "osd_nn_linear_bwd": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P]),
+    "osd_nn_bn_relu_dropout": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, _P, _P, _P, _P, C.c_double, C.c_double, C.c_int, C.c_int,
+                                         C.c_double, _P, C.c_uint64, C.c_uint32, _P, _P, _P]),
+    "osd_nn_bn_relu_dropout_bwd": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P,
+                                             C.c_uint64, C.c_uint32, _P, _P, _P]),
+    "osd_nn_reparameterize": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_uint64, C.c_int64, C.c_int, _P, _P]),
+    "osd_nn_reparameterize_bwd": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int64, _P]),
+    "osd_nn_clip_adamw_step": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                         C.c_double, C.c_double, C.c_int64, _P]),
+    "osd_nn_vae_loss": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "osd_nn_mixup": (C.c_int, [_P, C.c_int, _P, _P, C.c_double, C.c_int64, C.c_int, _P]),
+    "osd_nn_mse": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P, _P]),
     "osd_profile_step": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
     "osd_op_linear": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     "osd_op_linear_gn_silu": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int, _P]),

@@ -350,12 +350,8 @@ int osd_get_loss_parts(osd_handle* h, float* parts_host3) {
   return OSD_OK;
 }
 
-int osd_clip_adamw_step(osd_handle* h, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, double lr,
-                        double beta1, double beta2, double eps, double weight_decay, double max_norm, int64_t step, float* grad_norm_out) {
-  if (!h || !param || !grad || !exp_avg || !exp_avg_sq) { set_error("null argument"); return OSD_EINVAL; }
-  if (numel <= 0 || step < 1) { set_error("numel and step must be positive"); return OSD_EINVAL; }
-  OSD_HIP(hipSetDevice(h->cfg.device));
-  if (!h->normsq_dev) OSD_HIP(hipMalloc((void**)&h->normsq_dev, 64));
+static int clip_adamw(hipStream_t stream, double* normsq_ws, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                      double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm, int64_t step, float* grad_norm_out) {
   AdamArgs a{};
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
@@ -367,8 +363,28 @@ int osd_clip_adamw_step(osd_handle* h, float* param, float* grad, float* exp_avg
   a.eps = (float)eps;
   a.neg_step_size = (float)(-(lr / bc1));
   a.max_norm = (float)max_norm;
-  OSD_HIP(launch_clip_adamw(h->stream, param, grad, exp_avg, exp_avg_sq, numel, a, h->normsq_dev, grad_norm_out));
+  OSD_HIP(launch_clip_adamw(stream, param, grad, exp_avg, exp_avg_sq, numel, a, normsq_ws, grad_norm_out));
   return OSD_OK;
+}
+
+int osd_clip_adamw_step(osd_handle* h, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, double lr,
+                        double beta1, double beta2, double eps, double weight_decay, double max_norm, int64_t step, float* grad_norm_out) {
+  if (!h || !param || !grad || !exp_avg || !exp_avg_sq) { set_error("null argument"); return OSD_EINVAL; }
+  if (numel <= 0 || step < 1) { set_error("numel and step must be positive"); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  if (!h->normsq_dev) OSD_HIP(hipMalloc((void**)&h->normsq_dev, 64));
+  return clip_adamw(h->stream, h->normsq_dev, param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, max_norm, step,
+                    grad_norm_out);
+}
+
+int osd_nn_clip_adamw_step(void* stream, int device, double* normsq_ws, float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                           int64_t numel, double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm,
+                           int64_t step, float* grad_norm_out) {
+  if (!normsq_ws || !param || !grad || !exp_avg || !exp_avg_sq) { set_error("null argument"); return OSD_EINVAL; }
+  if (numel <= 0 || step < 1) { set_error("numel and step must be positive"); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(device));
+  return clip_adamw((hipStream_t)stream, normsq_ws, param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, max_norm, step,
+                    grad_norm_out);
 }
 
 }  // extern "C"

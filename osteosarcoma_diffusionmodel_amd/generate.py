@@ -109,17 +109,24 @@ def load_trained_model(checkpoint_path: Path, config: dict, device: str):
     logger.info(f"Loading model from {checkpoint_path}")
     checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
     state_dict = checkpoint["model_state_dict"]
-    saved_cond_dim = state_dict["condition_embed.mlp.0.weight"].shape[1]
+    arch = config["model"]["architecture"]
+    if arch not in ("diffusion", "cvae"):
+        raise ValueError(f"Unknown architecture: {arch}")
     processed = Path(config["data"]["processed_dir"])
     dims = []
     for fname in ("mutation_matrix_aligned.csv", "expression_matrix_aligned.csv", "pathway_scores.csv"):
         dims.append(pd.read_csv(processed / fname, index_col=0, nrows=1).shape[1])
-    arch = config["model"]["architecture"]
-    if arch != "diffusion":
-        raise ValueError(f"Unknown architecture: {arch}" if arch != "cvae" else
-                         "architecture 'cvae' is outside this package's hot path (SURVEY section 2)")
-    model = BiologyAwareDiffusionModel(mutation_dim=dims[0], expression_dim=dims[1], pathway_dim=dims[2],
-                                       condition_dim=saved_cond_dim, config=config)
+    if arch == "diffusion":
+        saved_cond_dim = state_dict["condition_embed.mlp.0.weight"].shape[1]
+        model = BiologyAwareDiffusionModel(mutation_dim=dims[0], expression_dim=dims[1], pathway_dim=dims[2],
+                                           condition_dim=saved_cond_dim, config=config)
+    else:
+        # the reference reads the diffusion key even for a cVAE checkpoint (utils/generate.py:250) and fails on it;
+        # here the condition width comes from the encoder's first Linear: in_features = data_dim + condition_dim
+        from .cvae import BiologyConstrainedVAE
+        saved_cond_dim = state_dict["vae.encoder.mlp.0.weight"].shape[1] - sum(dims)
+        model = BiologyConstrainedVAE(mutation_dim=dims[0], expression_dim=dims[1], pathway_dim=dims[2],
+                                      condition_dim=saved_cond_dim, config=config)
     model.load_state_dict(state_dict)
     model.to(device)
     model.eval()

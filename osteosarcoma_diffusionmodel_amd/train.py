@@ -132,13 +132,15 @@ class FusedAdamW(torch.optim.Optimizer):
     layout of ``torch.optim.AdamW`` (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``), so
     checkpoints interchange with the reference's."""
 
-    def __init__(self, model: BiologyAwareDiffusionModel, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=1e-2, max_norm: float = 0.0):
+    def __init__(self, model: nn.Module, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=1e-2, max_norm: float = 0.0, overwrites_grads: bool = True):
         super().__init__(flat.params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.model, self.flat, self.max_norm = model, flat, float(max_norm)
+        self.overwrites_grads = overwrites_grads      # the fused diffusion backward overwrites; autograd accumulates
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.grad_norm = torch.zeros(1, device=flat.flat.device)
+        self._normsq = torch.zeros(8, device=flat.flat.device, dtype=torch.float64)
         self._step = 0
         for p, o, n in zip(flat.params, flat.offsets[:-1], flat.numels):
             self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.exp_avg[o:o + n].view_as(p),
@@ -148,13 +150,14 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         g = self.param_groups[0]
         self._step += 1
-        eng = self.model._engine()
-        L.check(L.lib().osd_set_stream(eng.handle, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        L.check(L.lib().osd_clip_adamw_step(eng.handle, L.ptr(self.flat.flat), L.ptr(self.flat.grad), L.ptr(self.exp_avg),
-                                            L.ptr(self.exp_avg_sq), self.flat.flat.numel(), g["lr"], g["betas"][0], g["betas"][1],
-                                            g["eps"], g["weight_decay"], self.max_norm, self._step, L.ptr(self.grad_norm)))
-        for e in self.model._engines.values():      # weights changed behind autograd's back: the
-            e._sig = None                           # engine must refresh its derived tables
+        dev = self.flat.flat.device
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(L.lib().osd_nn_clip_adamw_step(stream, dev.index if dev.index is not None else torch.cuda.current_device(),
+                                               L.ptr(self._normsq), L.ptr(self.flat.flat), L.ptr(self.flat.grad), L.ptr(self.exp_avg),
+                                               L.ptr(self.exp_avg_sq), self.flat.flat.numel(), g["lr"], g["betas"][0], g["betas"][1],
+                                               g["eps"], g["weight_decay"], self.max_norm, self._step, L.ptr(self.grad_norm)))
+        for e in getattr(self.model, "_engines", {}).values():   # weights changed behind autograd's back: the
+            e._sig = None                                        # engine must refresh its derived tables
         return None
 
     def state_dict(self):
@@ -163,7 +166,9 @@ class FusedAdamW(torch.optim.Optimizer):
         return super().state_dict()
 
     def zero_grad(self, set_to_none: bool = True):
-        # gradients are overwritten (not accumulated) by osd_train_loss_fwd_bwd: nothing to clear
+        # osd_train_loss_fwd_bwd overwrites the gradients; autograd (the cVAE path) accumulates into the flat views
+        if not self.overwrites_grads:
+            self.flat.grad.zero_()
         return None
 
 
@@ -210,17 +215,17 @@ class MixupAugmentation:
         n = data.size(0)
         lam = np.random.beta(self.alpha, self.alpha) if self.alpha > 0 else 1.0
         index = torch.randperm(n)
-        if self.model is None or not data.is_cuda:
-            raise RuntimeError("MixupAugmentation runs on the device: construct it with model= and pass ROCm tensors "
-                               "(there is no CPU fallback)")
-        eng = self.model._engine()
+        if not data.is_cuda:
+            raise RuntimeError("MixupAugmentation runs on the device: pass ROCm tensors (there is no CPU fallback)")
         perm = index.to(data.device)
         d = data.float().contiguous()
         c = conditions.float().contiguous()
         s = survival.float().contiguous()
         od, oc, os_ = torch.empty_like(d), torch.empty_like(c), torch.empty_like(s)
-        L.check(L.lib().osd_mixup(eng.handle, L.ptr(d), L.ptr(c), L.ptr(s), L.ptr(perm), float(lam), n,
-                                  L.ptr(od), L.ptr(oc), L.ptr(os_)))
+        stream = C.c_void_p(torch.cuda.current_stream(data.device).cuda_stream)
+        dev = data.device.index if data.device.index is not None else torch.cuda.current_device()
+        for src, dst in ((d, od), (c, oc), (s, os_)):
+            L.check(L.lib().osd_nn_mixup(stream, dev, L.ptr(src), L.ptr(perm), float(lam), n, src.numel() // n, L.ptr(dst)))
         return {"data": od, "conditions": oc, "survival": os_}
 
 
@@ -257,11 +262,11 @@ class Trainer:
         self.model = model.to(device)
         self.train_loader, self.val_loader = train_loader, val_loader
         self.config, self.device = config, device
-        if hasattr(self.model, "vae"):
-            raise ValueError("BiologyConstrainedVAE is outside this package's hot path; use the reference trainer for it")
+        self.is_vae = hasattr(self.model, "vae")            # the reference's dispatch (utils/train.py:233)
         tc = config["training"]
         self.flat = FlatParams(self.model)
-        self.optimizer = FusedAdamW(self.model, self.flat, lr=tc["learning_rate"], weight_decay=tc["weight_decay"], max_norm=1.0)
+        self.optimizer = FusedAdamW(self.model, self.flat, lr=tc["learning_rate"], weight_decay=tc["weight_decay"], max_norm=1.0,
+                                    overwrites_grads=not self.is_vae)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", factor=0.5, patience=10)
         self.early_stopping = EarlyStopping(patience=tc["patience"], min_delta=tc["min_delta"])
         alpha = tc["augmentation"]["mixup_alpha"]
@@ -273,16 +278,19 @@ class Trainer:
         self.dist = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.world = torch.distributed.get_world_size() if self.dist else 1
         self.rank = torch.distributed.get_rank() if self.dist else 0
-        eng = self.model._engine()
-        nb = L.lib().osd_grad_buckets(C.byref(eng.cfg), None, None, 0)
-        first, last = (C.c_int32 * nb)(), (C.c_int32 * nb)()
-        L.lib().osd_grad_buckets(C.byref(eng.cfg), first, last, nb)
-        self.buckets = [(int(first[i]), int(last[i])) for i in range(nb)]
+        if self.is_vae:
+            self.buckets = [(0, len(self.flat.params) - 1)]      # one message after autograd's backward
+        else:
+            eng = self.model._engine()
+            nb = L.lib().osd_grad_buckets(C.byref(eng.cfg), None, None, 0)
+            first, last = (C.c_int32 * nb)(), (C.c_int32 * nb)()
+            L.lib().osd_grad_buckets(C.byref(eng.cfg), first, last, nb)
+            self.buckets = [(int(first[i]), int(last[i])) for i in range(nb)]
         self._slices = bucket_slices(self.flat.offsets, self.buckets)
         self._grad_ptrs = L.ptr_array(self.flat.grad_views)
         self._events = None
         self._comm_stream = None
-        if self.dist:
+        if self.dist and not self.is_vae:
             self._events = [torch.cuda.Event() for _ in self.buckets]
             for e in self._events:
                 e.record()            # materialise the hipEvent_t handles
@@ -290,9 +298,20 @@ class Trainer:
         self.global_step = 0
 
     # one optimisation step on an already device-resident (and mixed) batch
-    def train_step(self, data, conditions, *, t=None, noise=None, dropout_masks=None, seed=None) -> torch.Tensor:
+    def train_step(self, data, conditions, survival=None, *, t=None, noise=None, dropout_masks=None, seed=None, **vae_kw) -> torch.Tensor:
         if not self.flat.is_current():
             raise RuntimeError("model parameters were re-allocated after Trainer construction (e.g. model.to()); rebuild the Trainer")
+        if self.is_vae:
+            # BiologyConstrainedVAE (utils/train.py:233-234): autograd over the HIP layer ops; gradients land in the
+            # flat buffer's views, one all-reduce under data parallel, then the same fused clip + AdamW
+            self.optimizer.zero_grad()
+            loss = self.model(data, conditions, survival, seed=seed, **vae_kw)
+            (loss / self.world if self.dist else loss).backward()
+            if self.dist:
+                torch.distributed.all_reduce(self.flat.grad)
+            self.optimizer.step()
+            self.global_step += 1
+            return loss.detach()
         loss = _loss_fwd_bwd(self.model, data, conditions, self._grad_ptrs, t=t, noise=noise, dropout_masks=dropout_masks, seed=seed,
                              row_offset=self.rank * data.shape[0], loss_scale=1.0 / self.world, events=self._events)
         if self.dist:
@@ -311,8 +330,8 @@ class Trainer:
             survival = batch["survival"].to(self.device)
             if self.mixup is not None:
                 mixed = self.mixup({"data": data, "conditions": conditions, "survival": survival})
-                data, conditions = mixed["data"], mixed["conditions"]
-            total += self.train_step(data, conditions)
+                data, conditions, survival = mixed["data"], mixed["conditions"], mixed["survival"]
+            total += self.train_step(data, conditions, survival)
         return float(total.item()) / len(self.train_loader)
 
     @torch.no_grad()
@@ -323,7 +342,10 @@ class Trainer:
         for batch in self.val_loader:
             data = batch["data"].to(self.device)
             conditions = batch["conditions"].to(self.device)
-            total += _loss_fwd_bwd(self.model, data, conditions, None)
+            if self.is_vae:
+                total += self.model(data, conditions, batch["survival"].to(self.device))     # utils/train.py:265-266
+            else:
+                total += _loss_fwd_bwd(self.model, data, conditions, None)
         avg = total / max(len(self.val_loader), 1)
         if self.dist:
             torch.distributed.all_reduce(avg)

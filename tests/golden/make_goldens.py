@@ -417,12 +417,71 @@ def g9():
 
 
 
+def g10():
+    """cVAE (models/cvae.py): BiologyConstrainedVAE forward/backward in train and eval mode, sample/encode/decode."""
+    from models.cvae import BiologyConstrainedVAE
+    conf = {"model": {"latent_dim": 16, "hidden_dims": [32, 64, 32], "gnn": {"dropout": 0.2},
+                      "constraints": {"pathway_coherence_weight": 1.0, "mutation_expression_weight": 0.5,
+                                      "survival_prediction_weight": 0.3}}}
+    torch.manual_seed(3)
+    m = BiologyConstrainedVAE(8, 24, 8, 3, conf)
+    g = torch.Generator().manual_seed(17)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.copy_(1.0 + 0.3 * torch.randn(mod.weight.shape, generator=g))
+                mod.bias.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
+                mod.running_mean.copy_(0.1 * torch.randn(mod.running_mean.shape, generator=g))
+                mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g))
+    B, D, Lz = 6, 40, 16
+    x = torch.randn(B, D, generator=g)
+    x[:, :8] = (x[:, :8] > 0).float()
+    cond = torch.randn(B, 3, generator=g)
+    surv = torch.randn(B, generator=g)
+    eps = torch.randn(B, Lz, generator=g)
+    zs = torch.randn(B, Lz, generator=g)
+    out = {"x": x.numpy(), "cond": cond.numpy(), "survival": surv.numpy(), "eps": eps.numpy(), "z_sample": zs.numpy()}
+    out.update({f"sd.{k}": v for k, v in npd(m.state_dict()).items()})
+
+    # eval mode (running statistics, no dropout)
+    m.eval()
+    with Inject(randn_like=[eps, eps], randn=[zs]):
+        loss = m(x, cond, surv)
+        m.zero_grad()
+        loss.backward()
+        out["eval_loss"] = loss.detach().numpy()
+        for k, p_ in m.named_parameters():
+            out[f"eval_grad.{k}"] = p_.grad.detach().numpy().copy()
+        with torch.no_grad():
+            parts = m.vae(x, cond, return_parts=True)
+        for name, v in zip(["loss", "x_recon", "mu", "logvar", "recon_loss", "kl_loss"], parts):
+            out[f"eval_parts.{name}"] = v.detach().numpy()
+        out["eval_sample"] = m.sample(cond, num_samples=B).numpy()
+        out["eval_encode"] = m.vae.encode(x, cond).numpy()
+        out["eval_decode"] = m.vae.decode(zs, cond).numpy()
+
+    # train mode (batch statistics, running-stat update, dropout)
+    m.train()
+    with Inject(randn_like=[eps], drop_seed=29) as inj:
+        loss = m(x, cond, surv)
+        m.zero_grad()
+        loss.backward()
+        out["train_loss"] = loss.detach().numpy()
+        for k, p_ in m.named_parameters():
+            out[f"train_grad.{k}"] = p_.grad.detach().numpy().copy()
+        for i, mk in enumerate(inj.masks):
+            out[f"train_mask.{i}"] = mk.numpy()
+        assert len(inj.masks) == 7, len(inj.masks)
+    out.update({f"sd_after.{k}": v for k, v in npd(m.state_dict()).items() if "running" in k or "num_batches" in k})
+    save("g10_cvae", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        g1(); g2(); g3_g4(); g5(); g6(); g7(); g8(); g9()
+        g1(); g2(); g3_g4(); g5(); g6(); g7(); g8(); g9(); g10()
     # leave nothing behind in the read-only reference tree
     for pc in REF.rglob("__pycache__"):
         print("WARNING: bytecode dir appeared:", pc)

@@ -213,3 +213,39 @@ def test_g9_validation_metrics(golden_dir):
     c = [V.pearson(g["me_mut"][:, 0], g["me_pw"][:, 0]), V.pearson(g["me_mut"][:, 1], g["me_pw"][:, 1])]
     assert np.allclose(c, g["me.corr"], atol=1e-12)
     assert V.violation_rate(c, ["negative", "positive"]) == g["me.violation_rate"]
+
+
+def _cvae_args(g, mode):
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    x, cond, surv, eps = (torch.from_numpy(g[k]) for k in ("x", "cond", "survival", "eps"))
+    kw = dict(training=mode == "train", p=0.2)
+    if mode == "train":
+        m = [torch.from_numpy(g[f"train_mask.{i}"]) for i in range(7)]
+        kw.update(enc_masks=m[0:3], dec_masks=m[3:6], surv_mask=m[6])
+    return sd, (x, cond, surv, eps), kw
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_g10_cvae(golden_dir, mode):
+    """oracle/cvae_oracle.py against the reference's BiologyConstrainedVAE (models/cvae.py)."""
+    from oracle import cvae_oracle as V
+    g = load(golden_dir, "g10_cvae")
+    sd, args, kw = _cvae_args(g, mode)
+    new_stats = {}
+    out, grads = V.loss_and_grads(sd, *args, new_stats=new_stats, **kw)
+    close(out[0].detach(), g[f"{mode}_loss"], rtol=1e-6)
+    for k, gr in grads.items():
+        # a Linear bias in front of a training-mode BatchNorm has an exactly-zero gradient: fp32 noise ~1e-6 on both sides
+        close(gr, g[f"{mode}_grad.{k}"], rtol=2e-5, atol=3e-6)
+    if mode == "train":
+        for k, v in new_stats.items():
+            close(v, g[f"sd_after.{k}"], rtol=1e-6)
+    else:
+        assert not new_stats
+        parts = V.vae_forward(sd, args[0], args[1], args[3], False)
+        for name, v in zip(["loss", "x_recon", "mu", "logvar", "recon_loss", "kl_loss"], parts):
+            close(v, g[f"eval_parts.{name}"], rtol=1e-6)
+        z = torch.from_numpy(g["z_sample"])
+        close(V.decode(sd, z, args[1], False), g["eval_sample"], rtol=1e-6)
+        close(V.decode(sd, z, args[1], False), g["eval_decode"], rtol=1e-6)
+        close(V.encode(sd, args[0], args[1], False)[0], g["eval_encode"], rtol=1e-6)
