@@ -191,6 +191,14 @@ int osd_val_ks_extremes(void *stream, int device, const float *real, int64_t n1,
  * cols: host array of g column indices, 2 <= g <= 512. */
 int osd_val_mean_offdiag_corr(void *stream, int device, const float *data, int64_t rows, int ld,
                               const int32_t *cols_host, int g, double *out);
+/* Column sums (double) of data[:, :cols] -- the mutation frequencies of utils/validation.py:45-46 are sums / rows. */
+int osd_val_column_sums(void *stream, int device, const float *x, int64_t rows, int ld, int cols,
+                        double *sums_host);
+/* Raw Gram matrix of up to 64 selected columns: gram_host[i*g + j] = sum_r x[r][c_i] * x[r][c_j].  For 0/1 mutation
+ * columns these are the exact joint counts behind the 2x2 contingency tables of utils/validation.py:98-111 and
+ * the both-mutated counts of :75-78. */
+int osd_val_gram(void *stream, int device, const float *x, int64_t rows, int ld, const int32_t *cols_host,
+                 int g, double *gram_host);
 /* Pearson correlation of two strided device columns (Series.corr at utils/validation.py:205). */
 int osd_val_pearson(void *stream, int device, const float *a, int lda, const float *b, int ldb,
                     int64_t rows, double *out);

@@ -103,3 +103,51 @@ def violation_rate(corrs: Sequence[float], directions: Sequence[str]) -> float:
     """utils/validation.py:208-219."""
     v = sum(1 for c, d in zip(corrs, directions) if (d == "positive" and c < 0) or (d == "negative" and c > 0))
     return v / len(corrs)
+
+
+def chi2_from_counts(n: int, n1: int, n2: int, n11: int) -> float:
+    """chi2 statistic of scipy.stats.chi2_contingency(pd.crosstab(a, b)) for two 0/1 columns with n rows,
+    n1 = #(a == 1), n2 = #(b == 1), n11 = #(a == 1 and b == 1) (utils/validation.py:98-108).  crosstab only lists the
+    values that occur, so a constant column gives a one-row / one-column table (chi2 = 0)."""
+    from scipy import stats
+    table = np.array([[n - n1 - n2 + n11, n2 - n11], [n1 - n11, n11]], dtype=np.int64)
+    table = table[table.sum(1) > 0][:, table.sum(0) > 0]
+    return float(stats.chi2_contingency(table)[0])
+
+
+def mutation_cooccurrence(real: np.ndarray, synth: np.ndarray, names: Sequence[str], driver_genes: Sequence[str],
+                          exclusive_pairs: Sequence[Sequence[str]], picked: Sequence[int]) -> Dict[str, float]:
+    """utils/validation.py:27-121 for 0/1 matrices with identical columns; ``picked`` = the genes drawn by
+    np.random.choice at :91-93, in draw order."""
+    real, synth = np.asarray(real, dtype=np.float64), np.asarray(synth, dtype=np.float64)
+    idx = {g: i for i, g in enumerate(names)}
+    out = {"mutation_frequency_correlation": float(np.corrcoef(real.mean(0), synth.mean(0))[0, 1])}
+    drivers = [idx[g] for g in driver_genes if g in idx]
+    if drivers:
+        out["driver_gene_frequency_diff"] = float(np.abs(real[:, drivers].mean(0) - synth[:, drivers].mean(0)).mean())
+    viol = pairs = 0
+    for a, b in exclusive_pairs:
+        if a in idx and b in idx:
+            viol += int(((synth[:, idx[a]] == 1) & (synth[:, idx[b]] == 1)).sum())
+            pairs += 1
+    if pairs:
+        out["mutual_exclusivity_violation_rate"] = viol / (len(synth) * pairs)
+    cr, cs = [], []
+    for i, a in enumerate(picked):
+        for b in picked[i + 1:]:
+            for data, dst in ((real, cr), (synth, cs)):
+                x, y = data[:, a], data[:, b]
+                dst.append(chi2_from_counts(len(data), int(x.sum()), int(y.sum()), int((x * y).sum())))
+    if cr:
+        out["cooccurrence_pattern_correlation"] = float(np.corrcoef(cr, cs)[0, 1])
+    return out
+
+
+def wasserstein_pca_mean(real: np.ndarray, synth: np.ndarray, n_components: int = 10) -> float:
+    """utils/validation.py:256-269: PCA fitted on the real data, mean 1-D Wasserstein distance over the components."""
+    from scipy import stats
+    from sklearn.decomposition import PCA
+    pca = PCA(n_components=n_components)
+    rp = pca.fit_transform(real)
+    sp = pca.transform(synth)
+    return float(np.mean([stats.wasserstein_distance(rp[:, i], sp[:, i]) for i in range(n_components)]))

@@ -53,6 +53,12 @@ hipError_t cons_pathway(hipStream_t s, const ConsPlan& p, const ConsWs& w, const
 hipError_t cons_mutexpr(hipStream_t s, const ConsPlan& p, const ConsWs& w, const float* x_recon, const float* x_true, int ld, int64_t rows,
                         int cols, float w_loss, float w_grad, float* loss_out, float* part_out, float* dx);
 
+// building blocks shared with the validation metrics (validate.hip)
+// sum2[0..cols) += column sums, sum2[cols..2cols) += column sums of squares (double, pre-zeroed by the caller)
+hipError_t cons_column_sums(hipStream_t s, const float* x, int ld, int64_t rows, int cols, double* sum2);
+// C[i][j] (64 x 64 doubles, pre-zeroed) += sum_r zA[r][i] zB[r][j] with z = (x - mi.x) * mi.y of the selected columns (device index arrays)
+hipError_t cons_gram(hipStream_t s, const float* x, int ld, int64_t rows, const int* ca, int na, const int* cb, int nb, const float2* mi, double* C);
+
 // x0_hat = (x_t - sqrt_1m[t] * eps_hat) / sqrt_ac[t]  in place over eps_hat (models/diffusion.py:405)
 hipError_t launch_x0hat(hipStream_t s, const float* x_t, const int* t_idx, const float* sqrt_ac, const float* sqrt_1m, int64_t rows, int D,
                         float* eps_inout);

@@ -54,6 +54,12 @@ __global__ void k_cons_finish(const double* sum, const double* sumsq, int64_t ro
   const bool alive = var > 1e-12 * scale && var > 0.0;
   mi[c] = make_float2((float)m, alive ? (float)(1.0 / sqrt(var)) : 0.f);
 }
+hipError_t cons_column_sums(hipStream_t s, const float* x, int ld, int64_t rows, int cols, double* sum2) {
+  const int rpb = 256;
+  dim3 grid((cols + 63) / 64, (unsigned)((rows + rpb - 1) / rpb));
+  hipLaunchKernelGGL(k_cons_moments, grid, 256, 0, s, x, ld, rows, cols, rpb, sum2, sum2 + cols);
+  return hipGetLastError();
+}
 hipError_t cons_moments(hipStream_t s, const float* x, int ld, int64_t rows, int cols, double* sum2, float2* mi) {
   const int rpb = 256;
   dim3 grid((cols + 63) / 64, (unsigned)((rows + rpb - 1) / rpb));
@@ -254,6 +260,12 @@ __global__ void k_me_grad(const float* x, int ld, int64_t rows, const int* ca, i
     if (ga >= 0) atomicAdd(dx + r * ld + ga, ma.y * inv_nm1 * (aa - za * rowterm[lane]));
     if (gb >= 0) atomicAdd(dx + r * ld + gb, mb.y * inv_nm1 * (ab - zb * colterm[lane]));
   }
+}
+
+hipError_t cons_gram(hipStream_t s, const float* x, int ld, int64_t rows, const int* ca, int na, const int* cb, int nb, const float2* mi, double* C) {
+  const int rpb = 128;
+  hipLaunchKernelGGL(k_me_corr, (int)((rows + rpb - 1) / rpb), 256, 0, s, x, ld, rows, rpb, ca, na, cb, nb, mi, C);
+  return hipGetLastError();
 }
 
 hipError_t cons_mutexpr(hipStream_t st, const ConsPlan& p, const ConsWs& w, const float* x_recon, const float* x_true, int ld, int64_t rows,

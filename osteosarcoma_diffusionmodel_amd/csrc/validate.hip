@@ -246,6 +246,42 @@ int osd_val_mean_offdiag_corr(void* stream, int device, const float* data, int64
   return OSD_OK;
 }
 
+int osd_val_column_sums(void* stream, int device, const float* x, int64_t rows, int ld, int cols, double* sums_host) {
+  if (!x || !sums_host || rows < 1 || cols < 1 || ld < cols) { set_error("bad argument"); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  DevBuf d;
+  OSD_HIP(d.alloc((size_t)2 * cols * sizeof(double)));
+  OSD_HIP(hipMemsetAsync(d.p, 0, (size_t)2 * cols * sizeof(double), s));
+  OSD_HIP(cons_column_sums(s, x, ld, rows, cols, (double*)d.p));
+  OSD_HIP(hipMemcpyAsync(sums_host, d.p, (size_t)cols * sizeof(double), hipMemcpyDeviceToHost, s));
+  OSD_HIP(hipStreamSynchronize(s));
+  return OSD_OK;
+}
+
+int osd_val_gram(void* stream, int device, const float* x, int64_t rows, int ld, const int32_t* cols_host, int g, double* gram_host) {
+  if (!x || !cols_host || !gram_host || rows < 1 || g < 1 || g > CONS_MAX_SET) { set_error("bad argument (1 <= columns <= %d)", CONS_MAX_SET); return OSD_EINVAL; }
+  for (int i = 0; i < g; ++i)
+    if (cols_host[i] < 0 || cols_host[i] >= ld) { set_error("column index out of range"); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  DevBuf dc, dm, dC;
+  OSD_HIP(dc.alloc((size_t)g * sizeof(int)));
+  OSD_HIP(dm.alloc((size_t)ld * sizeof(float2)));
+  OSD_HIP(dC.alloc((size_t)CONS_MAX_SET * CONS_MAX_SET * sizeof(double)));
+  std::vector<float2> ident((size_t)ld, make_float2(0.f, 1.f));            // no standardisation: raw products
+  OSD_HIP(hipMemcpyAsync(dc.p, cols_host, (size_t)g * sizeof(int), hipMemcpyHostToDevice, s));
+  OSD_HIP(hipMemcpyAsync(dm.p, ident.data(), (size_t)ld * sizeof(float2), hipMemcpyHostToDevice, s));
+  OSD_HIP(hipMemsetAsync(dC.p, 0, (size_t)CONS_MAX_SET * CONS_MAX_SET * sizeof(double), s));
+  OSD_HIP(cons_gram(s, x, ld, rows, (const int*)dc.p, g, (const int*)dc.p, g, (const float2*)dm.p, (double*)dC.p));
+  std::vector<double> full((size_t)CONS_MAX_SET * CONS_MAX_SET);
+  OSD_HIP(hipMemcpyAsync(full.data(), dC.p, full.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  OSD_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < g; ++i)
+    for (int j = 0; j < g; ++j) gram_host[(size_t)i * g + j] = full[(size_t)i * CONS_MAX_SET + j];
+  return OSD_OK;
+}
+
 int osd_val_pearson(void* stream, int device, const float* a, int lda, const float* b, int ldb, int64_t rows, double* out) {
   if (!a || !b || !out || rows < 2) { set_error("bad argument"); return OSD_EINVAL; }
   OSD_HIP(hipSetDevice(device));

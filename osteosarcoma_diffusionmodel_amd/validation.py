@@ -1,10 +1,12 @@
-"""Validation metrics on MI355X -- host-side mirror of the part of the reference's utils/validation.py
-that consumes the sampler output at scale: RBF-MMD, per-feature two-sample KS,
-pathway coherence and the mutation-expression sign check.  Same method names and result keys as
-``BiologicalValidator``; the arithmetic runs in libosdiff.so (``osd_val_*``).
+"""Validation metrics on MI355X -- host-side mirror of the reference's utils/validation.py.
+Same class, method names and result keys as ``BiologicalValidator`` including ``validate_all``; everything that
+scales with the number of patients runs in libosdiff.so (``osd_val_*``): RBF-MMD, per-feature two-sample KS, pathway
+coherence, the mutation-expression sign check, mutation frequencies and the joint mutation counts behind the
+chi-square co-occurrence test and the mutual-exclusivity check.
 
-Not provided (outside the hot path): the chi-square co-occurrence test on a random
-gene subset (utils/validation.py:94-121) and the Wasserstein distance on PCA components (:256-269).
+Host-side by design, as SURVEY section 8f-1 prescribes: p-values and chi-square statistics from the exact device counts
+(``scipy.stats``), and the Wasserstein distance on 10 principal components (``sklearn`` PCA + ``scipy``, :256-269),
+which the reference itself computes that way.
 """
 from __future__ import annotations
 
@@ -82,7 +84,7 @@ class BiologicalValidator:
         res = [_ks_pvalue(r.shape[0], s.shape[0], int(dmax[i]), int(dmin[i])) for i in range(nf)]
         return np.array([d for d, _ in res]), np.array([p for _, p in res])
 
-    # -- utils/validation.py:225-271 (KS + MMD; the PCA/Wasserstein part is not provided) --------
+    # -- utils/validation.py:225-271 --------------------------------------------------------------
     def statistical_tests(self, real_data, synthetic_data) -> Dict[str, float]:
         logger.info("Running statistical tests...")
         _, pvals = self.ks_tests(real_data, synthetic_data)
@@ -91,7 +93,114 @@ class BiologicalValidator:
         logger.info(f"KS test mean p-value: {results['ks_test_mean_pvalue']:.3f}")
         logger.info(f"KS test fraction significant: {results['ks_test_fraction_significant']:.3f}")
         logger.info(f"MMD: {results['mmd']:.4f}")
+        # Wasserstein distance on the first 10 principal components (:256-269): host-side as in the reference
+        from scipy import stats
+        from sklearn.decomposition import PCA
+        host = [a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a.values if hasattr(a, "values") else a)
+                for a in (real_data, synthetic_data)]
+        pca = PCA(n_components=10)
+        real_pca, synth_pca = pca.fit_transform(host[0]), pca.transform(host[1])
+        results["wasserstein_distance_mean"] = float(np.mean([stats.wasserstein_distance(real_pca[:, i], synth_pca[:, i]) for i in range(10)]))
+        logger.info(f"Mean Wasserstein distance: {results['wasserstein_distance_mean']:.3f}")
         return results
+
+    # -- utils/validation.py:27-121 ----------------------------------------------------------------
+    def _column_sums(self, t: torch.Tensor) -> np.ndarray:
+        out = (C.c_double * t.shape[1])()
+        L.check(L.lib().osd_val_column_sums(self._stream(), self._dev_index, L.ptr(t), t.shape[0], t.shape[1], t.shape[1], out))
+        return np.frombuffer(out, dtype=np.float64).copy()
+
+    def _gram(self, t: torch.Tensor, cols) -> np.ndarray:
+        """Exact joint counts sum_r x[r][ci] x[r][cj] of 0/1 columns, 64 columns per device pass."""
+        cols = list(cols)
+        g = len(cols)
+        if g <= 64:
+            arr = (C.c_int32 * g)(*cols)
+            out = (C.c_double * (g * g))()
+            L.check(L.lib().osd_val_gram(self._stream(), self._dev_index, L.ptr(t), t.shape[0], t.shape[1], arr, g, out))
+            return np.frombuffer(out, dtype=np.float64).reshape(g, g).copy()
+        raise ValueError("at most 64 columns per Gram block")
+
+    @staticmethod
+    def _chi2(n: int, n1: int, n2: int, n11: int) -> float:
+        """chi2 of scipy.stats.chi2_contingency(pd.crosstab(a, b)) from the counts of two 0/1 columns (:98-108)."""
+        from scipy import stats
+        table = np.array([[n - n1 - n2 + n11, n2 - n11], [n1 - n11, n11]], dtype=np.int64)
+        table = table[table.sum(1) > 0][:, table.sum(0) > 0]      # crosstab lists only the values that occur
+        return float(stats.chi2_contingency(table)[0])
+
+    def validate_mutation_cooccurrence(self, real_mutations, synthetic_mutations) -> Dict[str, float]:
+        """real_mutations / synthetic_mutations: DataFrames of 0/1 columns named by gene."""
+        logger.info("Validating mutation co-occurrence patterns...")
+        results: Dict[str, float] = {}
+        common = real_mutations.columns.intersection(synthetic_mutations.columns)
+        r, s = _dev(real_mutations[common], self.device), _dev(synthetic_mutations[common], self.device)
+        pos = {g: i for i, g in enumerate(common)}
+        real_freq, synth_freq = self._column_sums(r) / r.shape[0], self._column_sums(s) / s.shape[0]
+        results["mutation_frequency_correlation"] = float(np.corrcoef(real_freq, synth_freq)[0, 1])
+        logger.info(f"Mutation frequency correlation: {results['mutation_frequency_correlation']:.3f}")
+        drivers = [g for g in self.driver_genes if g in real_mutations.columns]
+        if drivers:
+            rd = np.array([real_freq[pos[g]] if g in pos else float(real_mutations[g].mean()) for g in drivers])
+            sd = np.array([synth_freq[pos[g]] if g in pos else float(synthetic_mutations[g].mean()) for g in drivers])
+            results["driver_gene_frequency_diff"] = float(np.abs(rd - sd).mean())
+            logger.info(f"Driver gene frequency difference: {results['driver_gene_frequency_diff']:.3f}")
+        if self.mutually_exclusive_pairs:
+            pairs = [(a, b) for a, b in self.mutually_exclusive_pairs if a in synthetic_mutations.columns and b in synthetic_mutations.columns]
+            if pairs:
+                sfull = _dev(synthetic_mutations, self.device)
+                spos = {g: i for i, g in enumerate(synthetic_mutations.columns)}
+                violations = 0
+                for a, b in pairs:                       # both-mutated count = off-diagonal of the 2-column Gram block
+                    violations += int(round(self._gram(sfull, [spos[a], spos[b]])[0, 1]))
+                results["mutual_exclusivity_violation_rate"] = violations / (len(synthetic_mutations) * len(pairs))
+                logger.info(f"Mutual exclusivity violation rate: {results['mutual_exclusivity_violation_rate']:.3f}")
+        # pairwise chi-square on a random subset of at most 50 genes (np.random.choice, as the reference)
+        sample_genes = np.random.choice(common, size=min(50, len(common)), replace=False)
+        idx = [pos[g] for g in sample_genes]
+        if len(idx) >= 2:
+            gr, gs = self._gram(r, idx), self._gram(s, idx)
+            chi_r, chi_s = [], []
+            for i in range(len(idx)):
+                for j in range(i + 1, len(idx)):
+                    chi_r.append(self._chi2(r.shape[0], int(round(gr[i, i])), int(round(gr[j, j])), int(round(gr[i, j]))))
+                    chi_s.append(self._chi2(s.shape[0], int(round(gs[i, i])), int(round(gs[j, j])), int(round(gs[i, j]))))
+            results["cooccurrence_pattern_correlation"] = float(np.corrcoef(chi_r, chi_s)[0, 1])
+            logger.info(f"Co-occurrence pattern correlation: {results['cooccurrence_pattern_correlation']:.3f}")
+        return results
+
+    # -- utils/validation.py:300-383 ---------------------------------------------------------------
+    def validate_all(self, real_mutations, real_expression, real_pathways, synth_mutations, synth_expression, synth_pathways,
+                     pathway_gene_matrix=None) -> Dict[str, float]:
+        logger.info("=" * 50)
+        logger.info("BIOLOGICAL VALIDATION")
+        logger.info("=" * 50)
+        all_results: Dict[str, float] = {}
+        all_results.update(self.validate_mutation_cooccurrence(real_mutations, synth_mutations))
+        if pathway_gene_matrix is not None:
+            all_results.update(self.validate_pathway_coherence(real_expression, synth_expression, pathway_gene_matrix))
+        all_results.update(self.validate_mutation_expression_correlation(synth_mutations, synth_expression, synth_pathways))
+        real_combined = np.concatenate([real_mutations.values, real_expression.values, real_pathways.values], axis=1)
+        synth_combined = np.concatenate([synth_mutations.values, synth_expression.values, synth_pathways.values], axis=1)
+        all_results.update(self.statistical_tests(real_combined, synth_combined))
+        logger.info("=" * 50)
+        logger.info("VALIDATION SUMMARY")
+        logger.info("=" * 50)
+        for key, value in all_results.items():
+            logger.info(f"{key}: {value:.4f}")
+        score = []
+        if "mutation_frequency_correlation" in all_results:
+            score.append(all_results["mutation_frequency_correlation"])
+        if "cooccurrence_pattern_correlation" in all_results:
+            score.append(all_results["cooccurrence_pattern_correlation"])
+        if "mutual_exclusivity_violation_rate" in all_results:
+            score.append(1 - all_results["mutual_exclusivity_violation_rate"])
+        if "mutation_expression_violation_rate" in all_results:
+            score.append(1 - all_results["mutation_expression_violation_rate"])
+        if score:
+            all_results["overall_biological_score"] = float(np.mean(score))
+            logger.info(f"\nOverall Biological Score: {all_results['overall_biological_score']:.3f}")
+        return all_results
 
     # -- utils/validation.py:125-175 -------------------------------------------------------------
     def _mean_offdiag(self, data: torch.Tensor, cols) -> float:

@@ -413,6 +413,30 @@ def g9():
     out["me_mut"], out["me_pw"] = mut.values, pw.values
     out["me.violation_rate"] = np.float64(me["mutation_expression_violation_rate"])
     out["me.corr"] = np.array([mut["TP53"].corr(pw["HALLMARK_P53_PATHWAY"]), mut["MYC"].corr(pw["HALLMARK_MYC_TARGETS_V1"])])
+    out["stat.wasserstein_distance_mean"] = np.float64(st["wasserstein_distance_mean"])
+    # mutation co-occurrence (utils/validation.py:27-121): 60 genes incl. 4 of the 5 driver genes and the exclusive pair
+    names = ["TP53", "RB1", "ATRX", "PTEN", "MDM2", "MYC"] + [f"M{i}" for i in range(54)]
+    pr = rs.rand(60) * 0.5 + 0.1
+    real_m = (rs.rand(90, 60) < pr).astype(float)
+    synth_m = (rs.rand(70, 60) < np.clip(pr + 0.1 * rs.randn(60), 0.05, 0.9)).astype(float)
+    synth_m[:, 4] = np.where(synth_m[:, 0] == 1, (rs.rand(70) < 0.1).astype(float), synth_m[:, 4])   # TP53 / MDM2 mostly exclusive
+    rm, sm = pd.DataFrame(real_m, columns=names), pd.DataFrame(synth_m, columns=names)
+    np.random.seed(123)
+    co = val.validate_mutation_cooccurrence(rm, sm)
+    np.random.seed(123)
+    picked = np.random.choice(pd.Index(names), size=50, replace=False)
+    out["co_real"], out["co_synth"] = real_m, synth_m
+    out["co_picked"] = np.array([names.index(g) for g in picked])
+    for k, v in co.items():
+        out[f"co.{k}"] = np.float64(v)
+    # validate_all on the pieces above (70 synthetic / 90 real rows everywhere)
+    np.random.seed(123)
+    real_pw = rs.randn(90, 2)
+    out["all_real_pw"] = real_pw
+    allr = val.validate_all(rm, pd.DataFrame(real_e, columns=genes), pd.DataFrame(real_pw, columns=pw.columns),
+                            sm, pd.DataFrame(synth_e, columns=genes), pw, pgm)
+    for k, v in allr.items():
+        out[f"all.{k}"] = np.float64(v)
     save("g9_validation", **out)
 
 

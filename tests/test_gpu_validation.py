@@ -69,3 +69,53 @@ def test_metrics_at_scale_vs_oracle():
     assert abs(val._mean_offdiag(x, cols) - V.mean_offdiag_correlation(real, cols)) < 1e-6
     with pytest.raises(ValueError):
         val._mean_offdiag(x, [0])
+
+
+REF_EVAL = {"evaluation": {"driver_genes": ["TP53", "RB1", "ATRX", "DLG2", "PTEN"], "mutually_exclusive_pairs": [["TP53", "MDM2"]],
+                           "required_correlations": [{"mutation": "TP53", "pathway": "HALLMARK_P53_PATHWAY", "direction": "negative"},
+                                                     {"mutation": "MYC", "pathway": "HALLMARK_MYC_TARGETS_V1", "direction": "positive"}]}}
+CO_NAMES = ["TP53", "RB1", "ATRX", "PTEN", "MDM2", "MYC"] + [f"M{i}" for i in range(54)]
+
+
+def test_mutation_cooccurrence_vs_reference(golden_dir):
+    """Exact device counts -> the reference's numbers (frequencies, exclusivity, chi-square pattern correlation)."""
+    g = load_golden(golden_dir, "g9_validation")
+    val = BiologicalValidator(REF_EVAL)
+    rm, sm = pd.DataFrame(g["co_real"], columns=CO_NAMES), pd.DataFrame(g["co_synth"], columns=CO_NAMES)
+    np.random.seed(123)                                  # the seed the fixture was generated under (np.random.choice of 50 genes)
+    co = val.validate_mutation_cooccurrence(rm, sm)
+    assert set(co) == {k[3:] for k in g if k.startswith("co.")}
+    for k, v in co.items():
+        assert abs(v - g["co." + k]) < 1e-10, (k, v, g["co." + k])
+
+
+def test_validate_all_vs_reference(golden_dir):
+    g = load_golden(golden_dir, "g9_validation")
+    val = BiologicalValidator(REF_EVAL)
+    genes = [f"G{i}" for i in range(40)]
+    pw_cols = ["HALLMARK_P53_PATHWAY", "HALLMARK_MYC_TARGETS_V1"]
+    pgm = pd.DataFrame(g["coh_member"], index=[f"G{i}" for i in range(45)], columns=[f"P{i}" for i in range(12)])
+    np.random.seed(123)
+    res = val.validate_all(pd.DataFrame(g["co_real"], columns=CO_NAMES), pd.DataFrame(g["coh_real"], columns=genes),
+                           pd.DataFrame(g["all_real_pw"], columns=pw_cols), pd.DataFrame(g["co_synth"], columns=CO_NAMES),
+                           pd.DataFrame(g["coh_synth"], columns=genes), pd.DataFrame(g["me_pw"], columns=pw_cols), pgm)
+    assert set(res) == {k[4:] for k in g if k.startswith("all.") and k != "all_real_pw"}
+    tol = {"mmd": 1e-5, "wasserstein_distance_mean": 1e-4, "real_pathway_coherence": 1e-6, "synthetic_pathway_coherence": 1e-6,
+           "pathway_coherence_correlation": 1e-5}
+    for k, v in res.items():
+        assert abs(v - g["all." + k]) < tol.get(k, 1e-10), (k, v, g["all." + k])
+
+
+def test_gram_counts_at_scale():
+    """Joint counts of 64 binary columns over 300 001 rows are exact integers."""
+    rs = np.random.RandomState(5)
+    x = (rs.rand(300001, 70) < 0.3).astype(np.float32)
+    val = BiologicalValidator(REF_EVAL)
+    t = torch.from_numpy(x).cuda()
+    cols = list(range(3, 67))
+    gram = val._gram(t, cols)
+    ref = x[:, cols].astype(np.float64).T @ x[:, cols].astype(np.float64)
+    assert np.array_equal(gram, ref)
+    assert np.array_equal(val._column_sums(t), x.astype(np.float64).sum(0))
+    with pytest.raises(ValueError):
+        val._gram(t, list(range(65)))

@@ -249,3 +249,15 @@ def test_g10_cvae(golden_dir, mode):
         close(V.decode(sd, z, args[1], False), g["eval_sample"], rtol=1e-6)
         close(V.decode(sd, z, args[1], False), g["eval_decode"], rtol=1e-6)
         close(V.encode(sd, args[0], args[1], False)[0], g["eval_encode"], rtol=1e-6)
+
+
+def test_g9_cooccurrence_and_wasserstein(golden_dir):
+    from oracle import validation_oracle as V
+    g = load(golden_dir, "g9_validation")
+    names = ["TP53", "RB1", "ATRX", "PTEN", "MDM2", "MYC"] + [f"M{i}" for i in range(54)]
+    co = V.mutation_cooccurrence(g["co_real"], g["co_synth"], names, ["TP53", "RB1", "ATRX", "DLG2", "PTEN"], [["TP53", "MDM2"]],
+                                 g["co_picked"].tolist())
+    assert set(co) == {k[3:] for k in g if k.startswith("co.")}
+    for k, v in co.items():
+        assert abs(v - g["co." + k]) < 1e-10, k
+    assert abs(V.wasserstein_pca_mean(g["real"], g["synth"]) - g["stat.wasserstein_distance_mean"]) < 1e-5
