@@ -182,6 +182,9 @@ int osd_profile_step(osd_handle *h, const float *cond, int64_t n, int reps, floa
  * including the diagonal, sqrt(max(XX + YY - 2 XY, 0)).  X dev [n][D], Y dev [m][D]. */
 int osd_val_mmd(void *stream, int device, const float *X, int64_t n, const float *Y, int64_t m, int D,
                 double gamma, double *mmd_out);
+/* One block of the above for row-sharded data (multi-GPU validation): sum_out = sum_{i<n, j<m} exp(-gamma |a_i - b_j|^2). */
+int osd_val_rbf_sum(void *stream, int device, const float *A, int64_t n, const float *B, int64_t m, int D,
+                    double gamma, double *sum_out);
 /* scipy.stats.ks_2samp as used at utils/validation.py:238-245, for features 0..nf-1 of real dev [n1][ld]
  * and synth dev [n2][ld]: exact integer extremes of cnt(real<=v)*n2 - cnt(synth<=v)*n1 over all sample
  * points v; the statistic is max(dmax, -dmin, 0) / (n1*n2) (p-values follow on the host). */
@@ -199,7 +202,17 @@ int osd_val_column_sums(void *stream, int device, const float *x, int64_t rows, 
  * the both-mutated counts of :75-78. */
 int osd_val_gram(void *stream, int device, const float *x, int64_t rows, int ld, const int32_t *cols_host,
                  int g, double *gram_host);
-/* Pearson correlation of two strided device columns (Series.corr at utils/validation.py:205). */
+/* The two passes of osd_val_mean_offdiag_corr as partial sums over a row shard (all-reduce between them):
+ * per selected column sum and sum of squares; then S = sum_rows (sum_g (x - mu_g) * isd_g)^2. */
+int osd_val_col_moments(void *stream, int device, const float *data, int64_t rows, int ld,
+                        const int32_t *cols_host, int g, double *sum_host, double *sumsq_host);
+int osd_val_rowz_sq(void *stream, int device, const float *data, int64_t rows, int ld,
+                    const int32_t *cols_host, int g, const double *mu_host, const double *isd_host,
+                    double *S_host);
+/* Pearson correlation of two strided device columns (Series.corr at utils/validation.py:205); the five raw
+ * sums (sum a, sum b, sum a^2, sum b^2, sum ab) of a row shard. */
+int osd_val_pearson_sums(void *stream, int device, const float *a, int lda, const float *b, int ldb,
+                         int64_t rows, double *out5_host);
 int osd_val_pearson(void *stream, int device, const float *a, int lda, const float *b, int ldb,
                     int64_t rows, double *out);
 

@@ -61,6 +61,12 @@ _SIGNATURES = {
     "osd_val_mean_offdiag_corr": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
     "osd_val_column_sums": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "osd_val_gram": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
+    "osd_val_rbf_sum": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.c_int64, C.c_int, C.c_double, C.POINTER(C.c_double)]),
+    "osd_val_col_moments": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double)]),
+    "osd_val_rowz_sq": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "osd_val_pearson_sums": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int64, C.POINTER(C.c_double)]),
     "osd_val_pearson": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int64, C.POINTER(C.c_double)]),
     "osd_set_constraints": (C.c_int, [_P, C.POINTER(OsdConstraints)]),
     "osd_get_loss_parts": (C.c_int, [_P, C.POINTER(C.c_float)]),

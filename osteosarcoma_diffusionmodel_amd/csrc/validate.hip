@@ -170,6 +170,25 @@ int osd_val_mmd(void* stream, int device, const float* X, int64_t n, const float
   return OSD_OK;
 }
 
+int osd_val_rbf_sum(void* stream, int device, const float* A, int64_t n, const float* B, int64_t m, int D, double gamma, double* sum_out) {
+  if (!A || !B || !sum_out || n <= 0 || m <= 0 || D <= 0 || n > INT_MAX / 2 || m > INT_MAX / 2 || gamma <= 0) { set_error("bad argument (gamma must be > 0)"); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(device));
+  OSD_HIP(prepare_kernels());
+  hipStream_t s = (hipStream_t)stream;
+  DevBuf sq, sums;
+  OSD_HIP(sq.alloc((size_t)(n + m) * 4));
+  OSD_HIP(sums.alloc(sizeof(double)));
+  float* sqa = (float*)sq.p;
+  float* sqb = sqa + n;
+  OSD_HIP(hipMemsetAsync(sums.p, 0, sizeof(double), s));
+  hipLaunchKernelGGL(k_rowsumsq, 1024, 256, 0, s, A, n, D, sqa);
+  hipLaunchKernelGGL(k_rowsumsq, 1024, 256, 0, s, B, m, D, sqb);
+  OSD_HIP(rbf_sum(s, A, n, sqa, B, m, sqb, D, (float)gamma, (double*)sums.p));
+  OSD_HIP(hipMemcpyAsync(sum_out, sums.p, sizeof(double), hipMemcpyDeviceToHost, s));
+  OSD_HIP(hipStreamSynchronize(s));
+  return OSD_OK;
+}
+
 int osd_val_ks_extremes(void* stream, int device, const float* real, int64_t n1, const float* synth, int64_t n2, int ld, int nf,
                         int64_t* dmax_out, int64_t* dmin_out) {
   if (!real || !synth || !dmax_out || !dmin_out || n1 <= 0 || n2 <= 0 || nf <= 0 || nf > ld) { set_error("bad argument"); return OSD_EINVAL; }
@@ -211,37 +230,69 @@ int osd_val_ks_extremes(void* stream, int device, const float* real, int64_t n1,
   return OSD_OK;
 }
 
-int osd_val_mean_offdiag_corr(void* stream, int device, const float* data, int64_t rows, int ld, const int32_t* cols_host, int g,
-                              double* out) {
-  if (!data || !cols_host || !out || rows < 2 || g < 2 || g > 512) { set_error("bad argument (2 <= genes <= 512, rows >= 2)"); return OSD_EINVAL; }
+static int check_cols(const int32_t* cols_host, int g, int ld) {
+  if (!cols_host || g < 1 || g > 512) { set_error("bad column list (1 <= columns <= 512)"); return OSD_EINVAL; }
   for (int i = 0; i < g; ++i)
     if (cols_host[i] < 0 || cols_host[i] >= ld) { set_error("column index out of range"); return OSD_EINVAL; }
+  return OSD_OK;
+}
+
+int osd_val_col_moments(void* stream, int device, const float* data, int64_t rows, int ld, const int32_t* cols_host, int g,
+                        double* sum_host, double* sumsq_host) {
+  if (!data || !sum_host || !sumsq_host || rows < 1) { set_error("bad argument"); return OSD_EINVAL; }
+  OSD_TRY(check_cols(cols_host, g, ld));
   OSD_HIP(hipSetDevice(device));
   hipStream_t s = (hipStream_t)stream;
   DevBuf dc, dm;
   OSD_HIP(dc.alloc((size_t)g * sizeof(int)));
-  OSD_HIP(dm.alloc((size_t)(4 * g + 1) * sizeof(double)));
+  OSD_HIP(dm.alloc((size_t)2 * g * sizeof(double)));
   OSD_HIP(hipMemcpyAsync(dc.p, cols_host, (size_t)g * sizeof(int), hipMemcpyHostToDevice, s));
-  double* sum = (double*)dm.p; double* sumsq = sum + g; double* mu = sumsq + g; double* isd = mu + g; double* S = isd + g;
-  OSD_HIP(hipMemsetAsync(dm.p, 0, (size_t)(4 * g + 1) * sizeof(double), s));
+  OSD_HIP(hipMemsetAsync(dm.p, 0, (size_t)2 * g * sizeof(double), s));
   int blocks = (int)((rows + 15) / 16);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL((k_col_moments<8>), blocks, 256, 0, s, data, ld, rows, (const int*)dc.p, g, sum, sumsq);
+  hipLaunchKernelGGL((k_col_moments<8>), blocks, 256, 0, s, data, ld, rows, (const int*)dc.p, g, (double*)dm.p, (double*)dm.p + g);
   std::vector<double> hm((size_t)2 * g);
-  OSD_HIP(hipMemcpyAsync(hm.data(), sum, (size_t)2 * g * sizeof(double), hipMemcpyDeviceToHost, s));
+  OSD_HIP(hipMemcpyAsync(hm.data(), dm.p, (size_t)2 * g * sizeof(double), hipMemcpyDeviceToHost, s));
   OSD_HIP(hipStreamSynchronize(s));
-  std::vector<double> hmu((size_t)2 * g);
-  for (int i = 0; i < g; ++i) {
-    const double m = hm[i] / rows;
-    const double var = (hm[g + i] - rows * m * m) / (rows - 1);        // ddof = 1, as pandas .corr()
-    hmu[i] = m;
-    hmu[g + i] = var > 0 ? 1.0 / sqrt(var) : NAN;                       // constant column -> NaN, as pandas
-  }
-  OSD_HIP(hipMemcpyAsync(mu, hmu.data(), (size_t)2 * g * sizeof(double), hipMemcpyHostToDevice, s));
+  for (int i = 0; i < g; ++i) { sum_host[i] = hm[i]; sumsq_host[i] = hm[g + i]; }
+  return OSD_OK;
+}
+
+int osd_val_rowz_sq(void* stream, int device, const float* data, int64_t rows, int ld, const int32_t* cols_host, int g, const double* mu_host,
+                    const double* isd_host, double* S_host) {
+  if (!data || !mu_host || !isd_host || !S_host || rows < 1) { set_error("bad argument"); return OSD_EINVAL; }
+  OSD_TRY(check_cols(cols_host, g, ld));
+  OSD_HIP(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  DevBuf dc, dm;
+  OSD_HIP(dc.alloc((size_t)g * sizeof(int)));
+  OSD_HIP(dm.alloc((size_t)(2 * g + 1) * sizeof(double)));
+  double* mu = (double*)dm.p; double* isd = mu + g; double* S = isd + g;
+  OSD_HIP(hipMemcpyAsync(dc.p, cols_host, (size_t)g * sizeof(int), hipMemcpyHostToDevice, s));
+  OSD_HIP(hipMemcpyAsync(mu, mu_host, (size_t)g * sizeof(double), hipMemcpyHostToDevice, s));
+  OSD_HIP(hipMemcpyAsync(isd, isd_host, (size_t)g * sizeof(double), hipMemcpyHostToDevice, s));
+  OSD_HIP(hipMemsetAsync(S, 0, sizeof(double), s));
+  int blocks = (int)((rows + 15) / 16);
+  if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL((k_rowz_sq<8>), blocks, 256, 0, s, data, ld, rows, (const int*)dc.p, g, mu, isd, S);
-  double hs = 0;
-  OSD_HIP(hipMemcpyAsync(&hs, S, sizeof(double), hipMemcpyDeviceToHost, s));
+  OSD_HIP(hipMemcpyAsync(S_host, S, sizeof(double), hipMemcpyDeviceToHost, s));
   OSD_HIP(hipStreamSynchronize(s));
+  return OSD_OK;
+}
+
+int osd_val_mean_offdiag_corr(void* stream, int device, const float* data, int64_t rows, int ld, const int32_t* cols_host, int g,
+                              double* out) {
+  if (!data || !cols_host || !out || rows < 2 || g < 2 || g > 512) { set_error("bad argument (2 <= genes <= 512, rows >= 2)"); return OSD_EINVAL; }
+  std::vector<double> sum((size_t)g), sumsq((size_t)g), mu((size_t)g), isd((size_t)g);
+  OSD_TRY(osd_val_col_moments(stream, device, data, rows, ld, cols_host, g, sum.data(), sumsq.data()));
+  for (int i = 0; i < g; ++i) {
+    const double m = sum[i] / rows;
+    const double var = (sumsq[i] - rows * m * m) / (rows - 1);          // ddof = 1, as pandas .corr()
+    mu[i] = m;
+    isd[i] = var > 0 ? 1.0 / sqrt(var) : NAN;                           // constant column -> NaN, as pandas
+  }
+  double hs = 0;
+  OSD_TRY(osd_val_rowz_sq(stream, device, data, rows, ld, cols_host, g, mu.data(), isd.data(), &hs));
   *out = (hs / (rows - 1) - g) / ((double)g * (g - 1));
   return OSD_OK;
 }
@@ -282,8 +333,8 @@ int osd_val_gram(void* stream, int device, const float* x, int64_t rows, int ld,
   return OSD_OK;
 }
 
-int osd_val_pearson(void* stream, int device, const float* a, int lda, const float* b, int ldb, int64_t rows, double* out) {
-  if (!a || !b || !out || rows < 2) { set_error("bad argument"); return OSD_EINVAL; }
+int osd_val_pearson_sums(void* stream, int device, const float* a, int lda, const float* b, int ldb, int64_t rows, double* out5_host) {
+  if (!a || !b || !out5_host || rows < 1) { set_error("bad argument"); return OSD_EINVAL; }
   OSD_HIP(hipSetDevice(device));
   hipStream_t s = (hipStream_t)stream;
   DevBuf d;
@@ -292,9 +343,15 @@ int osd_val_pearson(void* stream, int device, const float* a, int lda, const flo
   int blocks = (int)((rows + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(k_pearson_sums, blocks, 256, 0, s, a, lda, b, ldb, rows, (double*)d.p);
-  double h[5];
-  OSD_HIP(hipMemcpyAsync(h, d.p, sizeof(h), hipMemcpyDeviceToHost, s));
+  OSD_HIP(hipMemcpyAsync(out5_host, d.p, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
   OSD_HIP(hipStreamSynchronize(s));
+  return OSD_OK;
+}
+
+int osd_val_pearson(void* stream, int device, const float* a, int lda, const float* b, int ldb, int64_t rows, double* out) {
+  if (!out || rows < 2) { set_error("bad argument"); return OSD_EINVAL; }
+  double h[5];
+  OSD_TRY(osd_val_pearson_sums(stream, device, a, lda, b, ldb, rows, h));
   const double n = (double)rows;
   const double cov = h[4] - h[0] * h[1] / n, va = h[2] - h[0] * h[0] / n, vb = h[3] - h[1] * h[1] / n;
   *out = cov / sqrt(va * vb);

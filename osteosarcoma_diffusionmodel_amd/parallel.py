@@ -41,3 +41,75 @@ def allreduce_buckets(flat_grad: torch.Tensor, slices: Sequence[Tuple[int, int]]
             comm_stream.wait_event(ev)
             dist.all_reduce(flat_grad[s:e])
     main.wait_stream(comm_stream)
+
+
+class ShardComm:
+    """The exchanges of row-sharded validation (third row): every rank holds a shard of the
+    synthetic patients; metric accumulators are summed, the few columns a sort needs are gathered, and the
+    all-pairs Gram block walks the shards by broadcast.  Inactive (world size 1 semantics) unless ``enabled`` and
+    ``torch.distributed`` is initialised.  Works on RCCL ("nccl", device tensors) and on gloo (staged through the
+    host), which is what the CPU tests drive."""
+
+    def __init__(self, enabled: bool = True):
+        self.on = bool(enabled) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.on else 1
+        self.rank = dist.get_rank() if self.on else 0
+        self._nccl = self.on and dist.get_backend() == "nccl"
+
+    def _stage(self, t: torch.Tensor) -> torch.Tensor:
+        if self._nccl:
+            return t if t.is_cuda else t.cuda()
+        return t.cpu()
+
+    def sum(self, values):
+        """Element-wise SUM over ranks of a float64 / int64 numpy array (or python scalar); returns numpy."""
+        import numpy as np
+        arr = np.atleast_1d(np.asarray(values))
+        if not self.on:
+            return arr.copy()
+        t = self._stage(torch.from_numpy(np.ascontiguousarray(arr)))
+        dist.all_reduce(t)
+        return t.cpu().numpy()
+
+    def gather_rows(self, t: torch.Tensor) -> torch.Tensor:
+        """Concatenation over ranks (rank order) of [n_r, cols] tensors with ragged n_r, on t's device."""
+        if not self.on:
+            return t
+        counts = self.sum(_one_hot(self.rank, self.world) * t.shape[0]).astype("int64")
+        nmax = int(counts.max())
+        pad = torch.zeros((nmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        staged = self._stage(pad.contiguous())
+        parts = [torch.empty_like(staged) for _ in range(self.world)]
+        dist.all_gather(parts, staged)
+        return torch.cat([p[: int(c)] for p, c in zip(parts, counts)], dim=0).to(t.device)
+
+    def shards(self, t: torch.Tensor):
+        """Yield every rank's [n_r, cols] tensor in rank order on t's device (one broadcast per rank, so the
+        working set is one shard, not the whole population)."""
+        if not self.on:
+            yield t
+            return
+        counts = self.sum(_one_hot(self.rank, self.world) * t.shape[0]).astype("int64")
+        for src in range(self.world):
+            if src == self.rank:
+                buf = self._stage(t.contiguous())
+            else:
+                buf = self._stage(torch.empty((int(counts[src]),) + tuple(t.shape[1:]), dtype=t.dtype,
+                                              device=t.device if self._nccl else "cpu"))
+            dist.broadcast(buf, src=src)
+            yield t if src == self.rank else buf.to(t.device)
+
+    def bcast_object(self, obj, src: int = 0):
+        if not self.on:
+            return obj
+        box = [obj]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+
+def _one_hot(i: int, n: int):
+    import numpy as np
+    v = np.zeros(n, dtype=np.int64)
+    v[i] = 1
+    return v

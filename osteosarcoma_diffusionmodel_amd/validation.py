@@ -7,18 +7,25 @@ chi-square co-occurrence test and the mutual-exclusivity check.
 Host-side by design, as SURVEY section 8f-1 prescribes: p-values and chi-square statistics from the exact device counts
 (``scipy.stats``), and the Wasserstein distance on 10 principal components (``sklearn`` PCA + ``scipy``, :256-269),
 which the reference itself computes that way.
+
+Multi-GPU (BASELINE config 5): ``BiologicalValidator(config, sharded=True)`` under an initialised
+``torch.distributed`` treats every *synthetic* argument as this rank's row shard (the real cohort is small and
+replicated).  Accumulators are summed over ranks (``parallel.ShardComm``), the all-pairs synthetic Gram block walks
+the shards by broadcast, the <= 100 KS columns are gathered and split by feature.  Every rank returns the same
+numbers as one process on the concatenated rows.
 """
 from __future__ import annotations
 
 import ctypes as C
 import logging
 from math import gcd
-from typing import Dict, Optional
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 import torch
 
 from . import _lib as L
+from .parallel import ShardComm
 
 logger = logging.getLogger(__name__)
 
@@ -29,6 +36,12 @@ def _dev(a, device) -> torch.Tensor:
         a = a.values
     t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
     return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _host(a) -> np.ndarray:
+    if isinstance(a, torch.Tensor):
+        return a.detach().cpu().numpy()
+    return np.asarray(a.values if hasattr(a, "values") else a)
 
 
 def _ks_pvalue(n1: int, n2: int, dmax: int, dmin: int):
@@ -45,10 +58,116 @@ def _ks_pvalue(n1: int, n2: int, dmax: int, dmin: int):
     return float(d), float(np.clip(distributions.kstwo.sf(d, np.round(m * n / (m + n))), 0, 1))
 
 
+class DeviceKernels:
+    """The per-shard partial results, each one libosdiff.so call on device tensors."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.index = device.index if device.index is not None else torch.cuda.current_device()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def rbf_sum(self, a: torch.Tensor, b: torch.Tensor, gamma: float) -> float:
+        out = C.c_double()
+        L.check(L.lib().osd_val_rbf_sum(self._stream(), self.index, L.ptr(a), a.shape[0], L.ptr(b), b.shape[0], a.shape[1], float(gamma),
+                                        C.byref(out)))
+        return float(out.value)
+
+    def ks_extremes(self, real: torch.Tensor, synth: torch.Tensor, nf: int):
+        dmax, dmin = (C.c_int64 * nf)(), (C.c_int64 * nf)()
+        L.check(L.lib().osd_val_ks_extremes(self._stream(), self.index, L.ptr(real), real.shape[0], L.ptr(synth), synth.shape[0],
+                                            real.shape[1], nf, dmax, dmin))
+        return np.array(dmax[:], dtype=np.int64), np.array(dmin[:], dtype=np.int64)
+
+    def col_moments(self, t: torch.Tensor, cols: Sequence[int]):
+        g = len(cols)
+        arr = (C.c_int32 * g)(*cols)
+        s, q = (C.c_double * g)(), (C.c_double * g)()
+        L.check(L.lib().osd_val_col_moments(self._stream(), self.index, L.ptr(t), t.shape[0], t.shape[1], arr, g, s, q))
+        return np.array(s[:]), np.array(q[:])
+
+    def rowz_sq(self, t: torch.Tensor, cols: Sequence[int], mu: np.ndarray, isd: np.ndarray) -> float:
+        g = len(cols)
+        arr = (C.c_int32 * g)(*cols)
+        out = C.c_double()
+        L.check(L.lib().osd_val_rowz_sq(self._stream(), self.index, L.ptr(t), t.shape[0], t.shape[1], arr, g, (C.c_double * g)(*mu),
+                                        (C.c_double * g)(*isd), C.byref(out)))
+        return float(out.value)
+
+    def pearson_sums(self, t_a: torch.Tensor, col_a: int, t_b: torch.Tensor, col_b: int) -> np.ndarray:
+        out = (C.c_double * 5)()
+        L.check(L.lib().osd_val_pearson_sums(self._stream(), self.index, C.c_void_p(t_a.data_ptr() + 4 * col_a), t_a.shape[1],
+                                             C.c_void_p(t_b.data_ptr() + 4 * col_b), t_b.shape[1], t_a.shape[0], out))
+        return np.array(out[:])
+
+    def column_sums(self, t: torch.Tensor) -> np.ndarray:
+        out = (C.c_double * t.shape[1])()
+        L.check(L.lib().osd_val_column_sums(self._stream(), self.index, L.ptr(t), t.shape[0], t.shape[1], t.shape[1], out))
+        return np.array(out[:])
+
+    def gram(self, t: torch.Tensor, cols: Sequence[int]) -> np.ndarray:
+        g = len(cols)
+        if g > 64:
+            raise ValueError("at most 64 columns per Gram block")
+        arr = (C.c_int32 * g)(*cols)
+        out = (C.c_double * (g * g))()
+        L.check(L.lib().osd_val_gram(self._stream(), self.index, L.ptr(t), t.shape[0], t.shape[1], arr, g, out))
+        return np.array(out[:]).reshape(g, g)
+
+
+# ---- combination of per-shard partials (pure host logic; the CPU tests drive it over gloo with numpy kernels) -----------
+def sharded_mmd(comm: ShardComm, k, x, y_local, gamma: float) -> float:
+    """utils/validation.py:273-298 with X replicated and Y row-sharded."""
+    n = x.shape[0]
+    m = int(comm.sum(y_local.shape[0])[0])
+    sxx = k.rbf_sum(x, x, gamma)
+    sxy = float(comm.sum(k.rbf_sum(x, y_local, gamma))[0])
+    syy_local = 0.0
+    for other in comm.shards(y_local):                 # rows of this shard against every shard: the row-block partition
+        syy_local += k.rbf_sum(y_local, other, gamma)
+    syy = float(comm.sum(syy_local)[0])
+    v = sxx / (float(n) * n) + syy / (float(m) * m) - 2.0 * sxy / (float(n) * m)
+    return float(np.sqrt(max(v, 0.0)))
+
+
+def sharded_ks_extremes(comm: ShardComm, k, real, synth_local, nf: int):
+    """Integer KS extremes of features 0..nf-1: the nf synthetic columns are gathered, the features split over ranks."""
+    synth = comm.gather_rows(synth_local[:, :nf].contiguous())
+    lo = (nf * comm.rank) // comm.world
+    hi = (nf * (comm.rank + 1)) // comm.world
+    dmax, dmin = np.zeros(nf, dtype=np.int64), np.zeros(nf, dtype=np.int64)
+    if hi > lo:
+        a, b = k.ks_extremes(real[:, lo:hi].contiguous(), synth[:, lo:hi].contiguous(), hi - lo)
+        dmax[lo:hi], dmin[lo:hi] = a, b
+    return comm.sum(dmax), comm.sum(dmin), int(synth.shape[0])
+
+
+def sharded_mean_offdiag(comm: ShardComm, k, data_local, cols: Sequence[int]) -> float:
+    """Mean off-diagonal Pearson correlation of data[:, cols] (utils/validation.py:156-161) over row shards."""
+    g = len(cols)
+    s, q = k.col_moments(data_local, cols)
+    tot = comm.sum(np.concatenate([s, q, [float(data_local.shape[0])]]))
+    rows = tot[-1]
+    mu = tot[:g] / rows
+    var = (tot[g:2 * g] - rows * mu * mu) / (rows - 1)              # ddof = 1, as pandas .corr()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        isd = np.where(var > 0, 1.0 / np.sqrt(var), np.nan)        # constant column -> NaN, as pandas
+    S = float(comm.sum(k.rowz_sq(data_local, cols, mu, isd))[0])
+    return (S / (rows - 1) - g) / (float(g) * (g - 1))
+
+
+def sharded_pearson(comm: ShardComm, k, a_local, col_a: int, b_local, col_b: int) -> float:
+    h = comm.sum(np.concatenate([k.pearson_sums(a_local, col_a, b_local, col_b), [float(a_local.shape[0])]]))
+    n = h[5]
+    cov, va, vb = h[4] - h[0] * h[1] / n, h[2] - h[0] * h[0] / n, h[3] - h[1] * h[1] / n
+    return float(cov / np.sqrt(va * vb))
+
+
 class BiologicalValidator:
     """utils/validation.py:18 -- device versions of the metrics named in the module docstring."""
 
-    def __init__(self, config: dict, device: str = "cuda"):
+    def __init__(self, config: dict, device: str = "cuda", sharded: bool = False):
         self.config = config
         ev = config.get("evaluation", {})
         self.driver_genes = ev.get("driver_genes", [])
@@ -57,10 +176,14 @@ class BiologicalValidator:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("the validation kernels run on a ROCm device; there is no CPU fallback")
-        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.k = DeviceKernels(self.device)
+        self.comm = ShardComm(sharded)            # synthetic rows sharded over ranks when active
+        self._one = ShardComm(False)              # the replicated real cohort never communicates
 
-    def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+    def _agree(self, result):
+        """Sharded mode: every rank reports rank 0's value (partial sums replicated per rank, e.g. over the real cohort,
+        can differ in the last bit between ranks because double atomics commit in any order)."""
+        return self.comm.bcast_object(result)
 
     # -- utils/validation.py:273-298 ----------------------------------------------------------
     def compute_mmd(self, X, Y, kernel: str = "rbf", gamma: Optional[float] = None) -> float:
@@ -69,20 +192,20 @@ class BiologicalValidator:
         x, y = _dev(X, self.device), _dev(Y, self.device)
         if x.shape[1] != y.shape[1]:
             raise ValueError("X and Y must have the same number of features")
-        out = C.c_double()
-        L.check(L.lib().osd_val_mmd(self._stream(), self._dev_index, L.ptr(x), x.shape[0], L.ptr(y), y.shape[0], x.shape[1],
-                                    float(gamma) if gamma else 0.0, C.byref(out)))
-        return float(out.value)
+        if not self.comm.on:
+            out = C.c_double()
+            L.check(L.lib().osd_val_mmd(self.k._stream(), self.k.index, L.ptr(x), x.shape[0], L.ptr(y), y.shape[0], x.shape[1],
+                                        float(gamma) if gamma else 0.0, C.byref(out)))
+            return float(out.value)
+        return self._agree(sharded_mmd(self.comm, self.k, x, y, float(gamma) if gamma else 1.0 / x.shape[1]))
 
     def ks_tests(self, real_data, synthetic_data, max_features: int = 100):
         """Per-feature (statistic, p-value) arrays for the first min(D, 100) features."""
         r, s = _dev(real_data, self.device), _dev(synthetic_data, self.device)
         nf = min(r.shape[1], max_features)
-        dmax, dmin = (C.c_int64 * nf)(), (C.c_int64 * nf)()
-        L.check(L.lib().osd_val_ks_extremes(self._stream(), self._dev_index, L.ptr(r), r.shape[0], L.ptr(s), s.shape[0], r.shape[1], nf,
-                                            dmax, dmin))
-        res = [_ks_pvalue(r.shape[0], s.shape[0], int(dmax[i]), int(dmin[i])) for i in range(nf)]
-        return np.array([d for d, _ in res]), np.array([p for _, p in res])
+        dmax, dmin, n2 = sharded_ks_extremes(self.comm, self.k, r, s, nf)
+        res = [_ks_pvalue(r.shape[0], n2, int(dmax[i]), int(dmin[i])) for i in range(nf)]
+        return self._agree((np.array([d for d, _ in res]), np.array([p for _, p in res])))
 
     # -- utils/validation.py:225-271 --------------------------------------------------------------
     def statistical_tests(self, real_data, synthetic_data) -> Dict[str, float]:
@@ -93,33 +216,26 @@ class BiologicalValidator:
         logger.info(f"KS test mean p-value: {results['ks_test_mean_pvalue']:.3f}")
         logger.info(f"KS test fraction significant: {results['ks_test_fraction_significant']:.3f}")
         logger.info(f"MMD: {results['mmd']:.4f}")
-        # Wasserstein distance on the first 10 principal components (:256-269): host-side as in the reference
+        # Wasserstein distance on the first 10 principal components (:256-269): host-side as in the reference; the
+        # PCA is fitted on the replicated real data, each rank projects its shard, the 10 projected columns are gathered
         from scipy import stats
         from sklearn.decomposition import PCA
-        host = [a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a.values if hasattr(a, "values") else a)
-                for a in (real_data, synthetic_data)]
         pca = PCA(n_components=10)
-        real_pca, synth_pca = pca.fit_transform(host[0]), pca.transform(host[1])
+        real_pca = pca.fit_transform(_host(real_data))
+        synth_pca = pca.transform(_host(synthetic_data))
+        if self.comm.on:
+            synth_pca = self.comm.gather_rows(torch.from_numpy(np.ascontiguousarray(synth_pca))).numpy()
         results["wasserstein_distance_mean"] = float(np.mean([stats.wasserstein_distance(real_pca[:, i], synth_pca[:, i]) for i in range(10)]))
         logger.info(f"Mean Wasserstein distance: {results['wasserstein_distance_mean']:.3f}")
-        return results
+        return self._agree(results)
 
     # -- utils/validation.py:27-121 ----------------------------------------------------------------
     def _column_sums(self, t: torch.Tensor) -> np.ndarray:
-        out = (C.c_double * t.shape[1])()
-        L.check(L.lib().osd_val_column_sums(self._stream(), self._dev_index, L.ptr(t), t.shape[0], t.shape[1], t.shape[1], out))
-        return np.frombuffer(out, dtype=np.float64).copy()
+        return self.k.column_sums(t)
 
     def _gram(self, t: torch.Tensor, cols) -> np.ndarray:
         """Exact joint counts sum_r x[r][ci] x[r][cj] of 0/1 columns, 64 columns per device pass."""
-        cols = list(cols)
-        g = len(cols)
-        if g <= 64:
-            arr = (C.c_int32 * g)(*cols)
-            out = (C.c_double * (g * g))()
-            L.check(L.lib().osd_val_gram(self._stream(), self._dev_index, L.ptr(t), t.shape[0], t.shape[1], arr, g, out))
-            return np.frombuffer(out, dtype=np.float64).reshape(g, g).copy()
-        raise ValueError("at most 64 columns per Gram block")
+        return self.k.gram(t, list(cols))
 
     @staticmethod
     def _chi2(n: int, n1: int, n2: int, n11: int) -> float:
@@ -135,39 +251,85 @@ class BiologicalValidator:
         results: Dict[str, float] = {}
         common = real_mutations.columns.intersection(synthetic_mutations.columns)
         r, s = _dev(real_mutations[common], self.device), _dev(synthetic_mutations[common], self.device)
+        n_synth = int(self.comm.sum(s.shape[0])[0])
         pos = {g: i for i, g in enumerate(common)}
-        real_freq, synth_freq = self._column_sums(r) / r.shape[0], self._column_sums(s) / s.shape[0]
+        real_freq, synth_freq = self._column_sums(r) / r.shape[0], self.comm.sum(self._column_sums(s)) / n_synth
         results["mutation_frequency_correlation"] = float(np.corrcoef(real_freq, synth_freq)[0, 1])
         logger.info(f"Mutation frequency correlation: {results['mutation_frequency_correlation']:.3f}")
+        sfull = _dev(synthetic_mutations, self.device)
+        spos = {g: i for i, g in enumerate(synthetic_mutations.columns)}
         drivers = [g for g in self.driver_genes if g in real_mutations.columns]
         if drivers:
-            rd = np.array([real_freq[pos[g]] if g in pos else float(real_mutations[g].mean()) for g in drivers])
-            sd = np.array([synth_freq[pos[g]] if g in pos else float(synthetic_mutations[g].mean()) for g in drivers])
+            sfreq_all = self.comm.sum(self._column_sums(sfull)) / n_synth
+            rd = np.array([float(real_mutations[g].mean()) for g in drivers])
+            sd = np.array([sfreq_all[spos[g]] for g in drivers])       # KeyError if a driver gene is missing, as the reference
             results["driver_gene_frequency_diff"] = float(np.abs(rd - sd).mean())
             logger.info(f"Driver gene frequency difference: {results['driver_gene_frequency_diff']:.3f}")
         if self.mutually_exclusive_pairs:
-            pairs = [(a, b) for a, b in self.mutually_exclusive_pairs if a in synthetic_mutations.columns and b in synthetic_mutations.columns]
+            pairs = [(a, b) for a, b in self.mutually_exclusive_pairs if a in spos and b in spos]
             if pairs:
-                sfull = _dev(synthetic_mutations, self.device)
-                spos = {g: i for i, g in enumerate(synthetic_mutations.columns)}
                 violations = 0
                 for a, b in pairs:                       # both-mutated count = off-diagonal of the 2-column Gram block
-                    violations += int(round(self._gram(sfull, [spos[a], spos[b]])[0, 1]))
-                results["mutual_exclusivity_violation_rate"] = violations / (len(synthetic_mutations) * len(pairs))
+                    violations += int(round(self.comm.sum(self._gram(sfull, [spos[a], spos[b]]).ravel())[1]))
+                results["mutual_exclusivity_violation_rate"] = violations / (n_synth * len(pairs))
                 logger.info(f"Mutual exclusivity violation rate: {results['mutual_exclusivity_violation_rate']:.3f}")
-        # pairwise chi-square on a random subset of at most 50 genes (np.random.choice, as the reference)
-        sample_genes = np.random.choice(common, size=min(50, len(common)), replace=False)
+        # pairwise chi-square on a random subset of at most 50 genes (np.random.choice, as the reference; rank 0 draws)
+        sample_genes = self.comm.bcast_object(list(np.random.choice(common, size=min(50, len(common)), replace=False)))
         idx = [pos[g] for g in sample_genes]
         if len(idx) >= 2:
-            gr, gs = self._gram(r, idx), self._gram(s, idx)
+            gr = self._gram(r, idx)
+            gs = self.comm.sum(self._gram(s, idx).ravel()).reshape(len(idx), len(idx))
             chi_r, chi_s = [], []
             for i in range(len(idx)):
                 for j in range(i + 1, len(idx)):
                     chi_r.append(self._chi2(r.shape[0], int(round(gr[i, i])), int(round(gr[j, j])), int(round(gr[i, j]))))
-                    chi_s.append(self._chi2(s.shape[0], int(round(gs[i, i])), int(round(gs[j, j])), int(round(gs[i, j]))))
+                    chi_s.append(self._chi2(n_synth, int(round(gs[i, i])), int(round(gs[j, j])), int(round(gs[i, j]))))
             results["cooccurrence_pattern_correlation"] = float(np.corrcoef(chi_r, chi_s)[0, 1])
             logger.info(f"Co-occurrence pattern correlation: {results['cooccurrence_pattern_correlation']:.3f}")
-        return results
+        return self._agree(results)
+
+    # -- utils/validation.py:125-175 -------------------------------------------------------------
+    def _mean_offdiag(self, data: torch.Tensor, cols, sharded: bool = False) -> float:
+        return sharded_mean_offdiag(self.comm if sharded else self._one, self.k, data, list(cols))
+
+    def validate_pathway_coherence(self, real_data, synthetic_data, pathway_gene_matrix) -> Dict[str, float]:
+        """real_data / synthetic_data: DataFrames with gene columns; pathway_gene_matrix: genes x pathways 0/1."""
+        logger.info("Validating pathway coherence...")
+        col_of = {g: i for i, g in enumerate(real_data.columns)}
+        syn_of = {g: i for i, g in enumerate(synthetic_data.columns)}
+        r, s = _dev(real_data, self.device), _dev(synthetic_data, self.device)
+        real_scores, synth_scores = [], []
+        for pathway in pathway_gene_matrix.columns[:10]:
+            genes = pathway_gene_matrix[pathway_gene_matrix[pathway] == 1].index
+            genes = [g for g in genes if g in col_of]
+            if len(genes) < 3:
+                continue
+            real_scores.append(self._mean_offdiag(r, [col_of[g] for g in genes]))
+            synth_scores.append(self._mean_offdiag(s, [syn_of[g] for g in genes], sharded=True))
+        results = {}
+        if real_scores:
+            results["real_pathway_coherence"] = float(np.mean(real_scores))
+            results["synthetic_pathway_coherence"] = float(np.mean(synth_scores))
+            results["pathway_coherence_correlation"] = float(np.corrcoef(real_scores, synth_scores)[0, 1])
+        return self._agree(results)
+
+    # -- utils/validation.py:177-223 -------------------------------------------------------------
+    def validate_mutation_expression_correlation(self, mutations, expression, pathway_scores) -> Dict[str, float]:
+        """All three arguments are synthetic data (row shards when the validator is sharded)."""
+        logger.info("Validating mutation-expression correlations...")
+        mut, pw = _dev(mutations, self.device), _dev(pathway_scores, self.device)
+        violations = total = 0
+        for rule in self.required_correlations:
+            gene, pathway, expected = rule["mutation"], rule["pathway"], rule["direction"]
+            if gene not in mutations.columns or pathway not in pathway_scores.columns:
+                continue
+            gi, pi = list(mutations.columns).index(gene), list(pathway_scores.columns).index(pathway)
+            corr = sharded_pearson(self.comm, self.k, mut, gi, pw, pi)
+            if (expected == "positive" and corr < 0) or (expected == "negative" and corr > 0):
+                violations += 1
+            total += 1
+            logger.info(f"{gene} vs {pathway}: corr={corr:.3f} (expected: {expected})")
+        return self._agree({"mutation_expression_violation_rate": violations / total} if total else {})
 
     # -- utils/validation.py:300-383 ---------------------------------------------------------------
     def validate_all(self, real_mutations, real_expression, real_pathways, synth_mutations, synth_expression, synth_pathways,
@@ -201,52 +363,3 @@ class BiologicalValidator:
             all_results["overall_biological_score"] = float(np.mean(score))
             logger.info(f"\nOverall Biological Score: {all_results['overall_biological_score']:.3f}")
         return all_results
-
-    # -- utils/validation.py:125-175 -------------------------------------------------------------
-    def _mean_offdiag(self, data: torch.Tensor, cols) -> float:
-        arr = (C.c_int32 * len(cols))(*cols)
-        out = C.c_double()
-        L.check(L.lib().osd_val_mean_offdiag_corr(self._stream(), self._dev_index, L.ptr(data), data.shape[0], data.shape[1], arr,
-                                                  len(cols), C.byref(out)))
-        return float(out.value)
-
-    def validate_pathway_coherence(self, real_data, synthetic_data, pathway_gene_matrix) -> Dict[str, float]:
-        """real_data / synthetic_data: DataFrames with gene columns; pathway_gene_matrix: genes x pathways 0/1."""
-        logger.info("Validating pathway coherence...")
-        col_of = {g: i for i, g in enumerate(real_data.columns)}
-        syn_of = {g: i for i, g in enumerate(synthetic_data.columns)}
-        r, s = _dev(real_data, self.device), _dev(synthetic_data, self.device)
-        real_scores, synth_scores = [], []
-        for pathway in pathway_gene_matrix.columns[:10]:
-            genes = pathway_gene_matrix[pathway_gene_matrix[pathway] == 1].index
-            genes = [g for g in genes if g in col_of]
-            if len(genes) < 3:
-                continue
-            real_scores.append(self._mean_offdiag(r, [col_of[g] for g in genes]))
-            synth_scores.append(self._mean_offdiag(s, [syn_of[g] for g in genes]))
-        results = {}
-        if real_scores:
-            results["real_pathway_coherence"] = float(np.mean(real_scores))
-            results["synthetic_pathway_coherence"] = float(np.mean(synth_scores))
-            results["pathway_coherence_correlation"] = float(np.corrcoef(real_scores, synth_scores)[0, 1])
-        return results
-
-    # -- utils/validation.py:177-223 -------------------------------------------------------------
-    def validate_mutation_expression_correlation(self, mutations, expression, pathway_scores) -> Dict[str, float]:
-        logger.info("Validating mutation-expression correlations...")
-        mut, pw = _dev(mutations, self.device), _dev(pathway_scores, self.device)
-        violations = total = 0
-        for rule in self.required_correlations:
-            gene, pathway, expected = rule["mutation"], rule["pathway"], rule["direction"]
-            if gene not in mutations.columns or pathway not in pathway_scores.columns:
-                continue
-            gi, pi = list(mutations.columns).index(gene), list(pathway_scores.columns).index(pathway)
-            out = C.c_double()
-            L.check(L.lib().osd_val_pearson(self._stream(), self._dev_index, C.c_void_p(mut.data_ptr() + 4 * gi), mut.shape[1],
-                                            C.c_void_p(pw.data_ptr() + 4 * pi), pw.shape[1], mut.shape[0], C.byref(out)))
-            corr = out.value
-            if (expected == "positive" and corr < 0) or (expected == "negative" and corr > 0):
-                violations += 1
-            total += 1
-            logger.info(f"{gene} vs {pathway}: corr={corr:.3f} (expected: {expected})")
-        return {"mutation_expression_violation_rate": violations / total} if total else {}

@@ -98,3 +98,103 @@ def test_bucketed_allreduce_is_the_mean_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ---- row-sharded validation (third row): the combination logic over gloo, numpy standing in for
+# ---- the device kernels (the GPU tests run the same functions with the real kernels) ---------------------------------
+class NumpyKernels:
+    """Per-shard partial results with the semantics of validation.DeviceKernels, float64 numpy."""
+
+    @staticmethod
+    def rbf_sum(a, b, gamma):
+        a, b = a.double().numpy(), b.double().numpy()
+        d2 = (a * a).sum(1)[:, None] + (b * b).sum(1)[None, :] - 2.0 * a @ b.T
+        return float(np.exp(-gamma * np.maximum(d2, 0.0)).sum())
+
+    @staticmethod
+    def ks_extremes(real, synth, nf):
+        from oracle import validation_oracle as V
+        ex = [V.ks_count_extremes(real[:, f].numpy(), synth[:, f].numpy()) for f in range(nf)]
+        return np.array([e[0] for e in ex], dtype=np.int64), np.array([e[1] for e in ex], dtype=np.int64)
+
+    @staticmethod
+    def col_moments(t, cols):
+        x = t.double().numpy()[:, cols]
+        return x.sum(0), (x * x).sum(0)
+
+    @staticmethod
+    def rowz_sq(t, cols, mu, isd):
+        z = (t.double().numpy()[:, cols] - mu) * isd
+        return float((z.sum(1) ** 2).sum())
+
+    @staticmethod
+    def pearson_sums(ta, ca, tb, cb):
+        x, y = ta.double().numpy()[:, ca], tb.double().numpy()[:, cb]
+        return np.array([x.sum(), y.sum(), (x * x).sum(), (y * y).sum(), (x * y).sum()])
+
+
+def _val_data():
+    rs = np.random.RandomState(4)
+    real = torch.from_numpy(rs.randn(60, 24).astype(np.float32))
+    synth = torch.from_numpy((rs.randn(101, 24) * 1.1 + 0.1).astype(np.float32))     # 101 rows: ragged shards
+    synth[:, 3] = torch.round(synth[:, 3])                                             # ties
+    return real, synth
+
+
+def _val_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import validation_oracle as V
+        from osteosarcoma_diffusionmodel_amd.parallel import ShardComm
+        from osteosarcoma_diffusionmodel_amd.validation import (sharded_ks_extremes, sharded_mean_offdiag, sharded_mmd,
+                                                                 sharded_pearson)
+        real, synth = _val_data()
+        off, cnt = shard_rows(synth.shape[0], rank, world)
+        local = synth[off:off + cnt].contiguous()
+        comm, k = ShardComm(True), NumpyKernels()
+        assert comm.on and comm.world == world
+        ok = True
+        gathered = comm.gather_rows(local)
+        ok &= torch.equal(gathered, synth)
+        ok &= all(torch.equal(s, synth[slice(*(lambda o, c: (o, o + c))(*shard_rows(synth.shape[0], r, world)))]) for r, s in enumerate(comm.shards(local)))
+        ok &= abs(sharded_mmd(comm, k, real, local, 1.0 / 24) - V.mmd_rbf(real.numpy(), synth.numpy())) < 1e-9
+        dmax, dmin, n2 = sharded_ks_extremes(comm, k, real, local, 10)
+        ref = [V.ks_count_extremes(real[:, f].numpy(), synth[:, f].numpy()) for f in range(10)]
+        ok &= n2 == 101 and dmax.tolist() == [r[0] for r in ref] and dmin.tolist() == [r[1] for r in ref]
+        cols = [1, 4, 5, 9, 20]
+        ok &= abs(sharded_mean_offdiag(comm, k, local, cols) - V.mean_offdiag_correlation(synth.numpy(), cols)) < 1e-9
+        ok &= abs(sharded_pearson(comm, k, local, 2, local, 7) - V.pearson(synth.numpy()[:, 2], synth.numpy()[:, 7])) < 1e-9
+        ok &= comm.bcast_object(("x", rank)) == ("x", 0)
+        ok &= comm.sum(np.array([rank + 1, 10], dtype=np.int64)).tolist() == [3, 20]
+        q.put((rank, bool(ok)))
+    except Exception as e:                           # report instead of leaving the parent to time out
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_validation_combination_gloo_world2():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_val_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_shardcomm_inactive_is_identity():
+    from osteosarcoma_diffusionmodel_amd.parallel import ShardComm
+    c = ShardComm(True)                              # no process group: behaves as world size 1
+    t = torch.arange(6.0).view(3, 2)
+    assert not c.on and c.world == 1
+    assert c.gather_rows(t) is t and list(c.shards(t))[0] is t
+    assert c.sum(5).tolist() == [5] and c.bcast_object("a") == "a"
