@@ -2,6 +2,7 @@
 // fused forward + backward of the eps-prediction MSE loss, mixup lives in api.hip,
 // clip_grad_norm_ + AdamW over flat buffers.
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 #include "handle.h"
 #include "kernels.h"
@@ -68,7 +69,8 @@ static hipError_t wgrad(hipStream_t s, const TrainWs& w, const float* x, int ldx
   GemmArgs g{};
   g.A = x; g.lda = ldx; g.B0 = gz; g.ldb0 = ldg; g.K0 = (int)rows; g.F = kin; g.P = nout; g.K = (int)rows;
   const long tiles = (long)((kin + 63) / 64) * ((nout + 63) / 64);
-  int slices = (int)((512 + tiles - 1) / tiles);
+  static const int target = [] { const char* e = getenv("OSD_WGRAD_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+  int slices = (int)((target + tiles - 1) / tiles);
   const int max_slices = (int)((rows + 127) / 128);
   if (slices > max_slices) slices = max_slices;
   const int64_t numel = (int64_t)nout * kin;

@@ -146,6 +146,8 @@ def sharded_ks_extremes(comm: ShardComm, k, real, synth_local, nf: int):
 def sharded_mean_offdiag(comm: ShardComm, k, data_local, cols: Sequence[int]) -> float:
     """Mean off-diagonal Pearson correlation of data[:, cols] (utils/validation.py:156-161) over row shards."""
     g = len(cols)
+    if g < 2:
+        raise ValueError("a mean off-diagonal correlation needs at least 2 columns")
     s, q = k.col_moments(data_local, cols)
     tot = comm.sum(np.concatenate([s, q, [float(data_local.shape[0])]]))
     rows = tot[-1]
