@@ -34,10 +34,24 @@ int persist_mode() {
   }
   return mode;
 }
+static int g_ws_mode = -1;
+int ws_mode() {
+  if (g_ws_mode < 0) {
+    const char* e = getenv("OSD_WS");
+    g_ws_mode = e ? atoi(e) : 0;
+  }
+  return g_ws_mode;
+}
+static bool g_ws_available = true;
+bool ws_available() { return g_ws_available; }
 hipError_t prepare_kernels() {
   for (const KernelReg& k : kernel_registry()) {
     hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.lds_bytes);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) {
+      if (!k.optional) return e;
+      g_ws_available = false;          // the 160 KB wave-specialised variant is an optimisation: fall back to gemm_glds_kernel
+      (void)hipGetLastError();
+    }
   }
   return hipSuccess;
 }
@@ -348,6 +362,11 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "n_streams")) {
     if (value < 1 || value > 8) { set_error("n_streams must be in [1,8]"); return OSD_EINVAL; }
     h->n_streams = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "wave_specialized")) {       // process-wide: 0 off, 1 for launches of >= 512 tiles, 2 whenever the 128x128 tile is used
+    if (value < 0 || value > 2) { set_error("wave_specialized must be 0, 1 or 2"); return OSD_EINVAL; }
+    g_ws_mode = (int)value;
     return OSD_OK;
   }
   if (!strcmp(name, "train_streams")) {

@@ -29,10 +29,18 @@ __device__ __forceinline__ float swap_halves(float v) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Hook called by every epilogue after each unit of work (an accumulator quad, a group statistic).  The
+// wave-specialised kernel (gemm_ws.h) passes a TickSync that turns some of the calls into workgroup barriers so that
+// an epilogue wave keeps rendezvousing with the MFMA waves' K loop; everywhere else it is this no-op.
+struct NoSync {
+  __device__ __forceinline__ void tick() {}
+};
+
 // ---- bias (+ optional SiLU, + optional accumulate into out) -----------------------
 template <bool SILU, bool ACCUM>
 struct EpiBias {
   static constexpr bool COUNTED_STORES = true;    // one float4 store per accumulator quad on a full tile
+  static constexpr int WS_SLICES = 8;             // gemm_ws.h: barriers placed inside the epilogue
   struct Args { const float* bias; float* out; int ldo; long long slice_stride; };
   static bool fast_ok(const Args& a, int F) { return F % 4 == 0 && al16(a.bias) && al16(a.out) && a.ldo % 4 == 0 && a.slice_stride % 4 == 0; }
   static __device__ __forceinline__ void slice(Args& a, int y) { a.out += (long long)y * a.slice_stride; }
@@ -48,8 +56,9 @@ struct EpiBias {
         r.bias[fb][q] = a.bias ? ldq<FAST>(a.bias, fw + 32 * fb + 8 * q + 4 * h, F) : make_float4(0.f, 0.f, 0.f, 0.f);
     return r;
   }
-  template <int NFB, int NPB, bool FAST>
-  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P) {
+  template <int NFB, int NPB, bool FAST, class Sync = NoSync>
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P,
+                                               Sync&& sync = Sync()) {
     const int l31 = lane & 31, h = lane >> 5;
     OSD_FOR_QUADS(fb, pb, q) {
       const int f = fw + 32 * fb + 8 * q + 4 * h;
@@ -61,6 +70,7 @@ struct EpiBias {
       if (ACCUM) { const float4 o = ldq<FAST>(row, f, F); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
       if (SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
       if (p < P) stq<FAST>(row, f, F, v);
+      sync.tick();
     }
   }
 };
@@ -68,6 +78,7 @@ struct EpiBias {
 // ---- input_proj: h = ((x W^T + b) + t_emb[t]) + c_proj   (models/diffusion.py:229-232) ----
 struct EpiInput {
   static constexpr bool COUNTED_STORES = true;
+  static constexpr int WS_SLICES = 3;             // t_emb / c_proj quads are loaded inside the slices: few, long slices
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias;
@@ -91,8 +102,9 @@ struct EpiInput {
       for (int q = 0; q < 4; ++q) r.bias[fb][q] = ldq<FAST>(a.bias, fw + 32 * fb + 8 * q + 4 * h, F);
     return r;
   }
-  template <int NFB, int NPB, bool FAST>
-  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P) {
+  template <int NFB, int NPB, bool FAST, class Sync = NoSync>
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P,
+                                               Sync&& sync = Sync()) {
     const int l31 = lane & 31, h = lane >> 5;
     const int t_shared = a.t_dev ? *a.t_dev : a.t_imm;
 #pragma unroll
@@ -115,6 +127,7 @@ struct EpiInput {
           v.z = ((acc[fb][pb][4 * q + 2] + bv.z) + tv.z) + cv.z;
           v.w = ((acc[fb][pb][4 * q + 3] + bv.w) + tv.w) + cv.w;
           if (p < P) stq<FAST>(orow, f, F, v);
+          sync.tick();
         }
     }
   }
@@ -130,6 +143,7 @@ struct EpiInput {
 template <int GW, bool DROP>
 struct EpiGnSilu {
   static constexpr bool COUNTED_STORES = true;
+  static constexpr int WS_SLICES = 8;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias; const float* gamma; const float* beta;
@@ -163,8 +177,9 @@ struct EpiGnSilu {
       }
     return r;
   }
-  template <int NFB, int NPB, bool FAST>
-  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P) {
+  template <int NFB, int NPB, bool FAST, class Sync = NoSync>
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P,
+                                               Sync&& sync = Sync()) {
     static_assert(NFB * 32 >= GW, "wave must own whole groups");
     constexpr int RPG = (GW >= 8) ? GW / 2 : 4;   // registers of one group in this lane
     constexpr int NG = NFB * 16 / RPG;
@@ -200,6 +215,7 @@ struct EpiGnSilu {
         if (GW >= 8) qs += swap_halves(qs);
         mean[g] = m;
         rstd[g] = 1.0f / sqrtf(qs * (1.0f / GW) + GN_EPS);
+        sync.tick();
       }
       float* orow = a.out + (size_t)pc * a.ldo;
 #pragma unroll
@@ -234,6 +250,7 @@ struct EpiGnSilu {
             y.w *= (u01(r.w) >= a.p_drop) ? a.keep_scale : 0.f;
           }
           if (prow) stq<FAST>(orow, f, F, y);
+          sync.tick();
         }
     }
   }
@@ -249,6 +266,7 @@ struct EpiGnSilu {
 // differs from the reference's op order by a few ulp of the same intermediate magnitudes.
 struct EpiPosterior {
   static constexpr bool COUNTED_STORES = true;
+  static constexpr int WS_SLICES = 8;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias;
@@ -276,20 +294,28 @@ struct EpiPosterior {
       for (int q = 0; q < 4; ++q) r.bias[fb][q] = ldq<FAST>(a.bias, fw + 32 * fb + 8 * q + 4 * h, F);
     return r;
   }
-  template <int NFB, int NPB, bool FAST>
-  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P) {
+  template <int NFB, int NPB, bool FAST, class Sync = NoSync>
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P,
+                                               Sync&& sync = Sync()) {
     const int l31 = lane & 31, h = lane >> 5;
     const int t = a.t_dev ? *a.t_dev : a.t_imm;
     const float* c = a.coef + 4 * t;
     const float cA = c[0], cB = c[1], cC = c[2];
     const float* zbase = a.z ? a.z + (long long)(a.t_first - t) * a.z_step_stride : nullptr;
+    // every x_t quad of the wave's tile is requested before the first one is used (one latency, not sixteen; the
+    // wave-specialised kernel places barriers between quads, which the compiler will not move loads across)
+    float4 xq[NFB][NPB][4];
+    OSD_FOR_QUADS(fb, pb, q) {
+      const int p = pw + 32 * pb + l31;
+      xq[fb][pb][q] = ldq<FAST>(a.xin + (size_t)(p < P ? p : P - 1) * a.ldx, fw + 32 * fb + 8 * q + 4 * h, F);
+    }
     OSD_FOR_QUADS(fb, pb, q) {
       const int f = fw + 32 * fb + 8 * q + 4 * h;
       const int p = pw + 32 * pb + l31;
       const int pc = p < P ? p : P - 1;
       const bool ok = p < P && f < F;
       const float4 bv = pre.bias[fb][q];
-      const float4 x = ldq<FAST>(a.xin + (size_t)pc * a.ldx, f, F);
+      const float4 x = xq[fb][pb][q];
       const float e[4] = {acc[fb][pb][4 * q] + bv.x, acc[fb][pb][4 * q + 1] + bv.y, acc[fb][pb][4 * q + 2] + bv.z, acc[fb][pb][4 * q + 3] + bv.w};
       const float xv[4] = {x.x, x.y, x.z, x.w};
       float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -308,6 +334,7 @@ struct EpiPosterior {
           if (f + r < a.mutation_dim) mrow[f + r] = (o[r] > 0.5f) ? 1.0f : 0.0f;
       }
       if (p < P) stq<FAST>(a.xout + (size_t)pc * a.ldo, f, F, make_float4(o[0], o[1], o[2], o[3]));
+      sync.tick();
     }
   }
 };
@@ -316,6 +343,7 @@ struct EpiPosterior {
 // d = (acc + bias) - noise;  loss += sum d^2 * inv_count;  dout = d * gscale
 struct EpiMse {
   static constexpr bool COUNTED_STORES = false;   // dout / pred are optional
+  static constexpr int WS_SLICES = 4;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias; const float* noise; int ldn;
@@ -339,8 +367,9 @@ struct EpiMse {
       for (int q = 0; q < 4; ++q) r.bias[fb][q] = ldq<FAST>(a.bias, fw + 32 * fb + 8 * q + 4 * h, F);
     return r;
   }
-  template <int NFB, int NPB, bool FAST>
-  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P) {
+  template <int NFB, int NPB, bool FAST, class Sync = NoSync>
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P,
+                                               Sync&& sync = Sync()) {
     const int l31 = lane & 31, h = lane >> 5;
     float part = 0.f;
     OSD_FOR_QUADS(fb, pb, q) {
@@ -359,6 +388,7 @@ struct EpiMse {
       if (!prow || f + 3 >= F) d.w = 0.f;
       part += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
       if (a.dout && prow) stq<FAST>(a.dout + (size_t)p * a.ldd, f, F, make_float4(d.x * a.gscale, d.y * a.gscale, d.z * a.gscale, d.w * a.gscale));
+      sync.tick();
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
@@ -370,6 +400,7 @@ struct EpiMse {
 // acc = x_f . y_p;  d2 = |x_f|^2 + |y_p|^2 - 2 acc;  sum += exp(-gamma * max(d2, 0)) over the valid tile
 struct EpiRbfSum {
   static constexpr bool COUNTED_STORES = false;   // stores nothing
+  static constexpr int WS_SLICES = 4;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args { const float* sqa; const float* sqb; float gamma; double* sum; };
   static bool fast_ok(const Args& a, int F) { return F % 4 == 0 && al16(a.sqa); }
@@ -384,8 +415,9 @@ struct EpiRbfSum {
       for (int q = 0; q < 4; ++q) r.sqa[fb][q] = ldq<FAST>(a.sqa, fw + 32 * fb + 8 * q + 4 * h, F);
     return r;
   }
-  template <int NFB, int NPB, bool FAST>
-  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P) {
+  template <int NFB, int NPB, bool FAST, class Sync = NoSync>
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P,
+                                               Sync&& sync = Sync()) {
     const int l31 = lane & 31, h = lane >> 5;
     float part = 0.f;
 #pragma unroll
