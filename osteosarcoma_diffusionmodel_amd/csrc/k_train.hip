@@ -95,9 +95,11 @@ hipError_t launch_scatter_rows(hipStream_t s, const float* g, const int* t, int6
 //   y = zhat*gamma + beta, a = silu(y), out = a * keep
 //   g_y = g*keep*silu'(y);  g_zhat = g_y*gamma
 //   g_z = rstd * (g_zhat - mean_g(g_zhat) - zhat*mean_g(g_zhat*zhat))
+constexpr int GN_BWD_WAVES = 16;     // waves per block: at a training batch of 4096 rows every wave owns one row (4 waves per SIMD)
 template <int GW, int NJ>
-__global__ __launch_bounds__(256) void k_gn_silu_bwd(GnBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float red[];      // [3][4 waves][C]
+__global__ __launch_bounds__(64 * GN_BWD_WAVES) void k_gn_silu_bwd(GnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];      // [3][waves of the block][C]
+  const int NW = blockDim.x >> 6;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -170,15 +172,17 @@ __global__ __launch_bounds__(256) void k_gn_silu_bwd(GnBwdArgs a) {
     for (int e = 0; e < 4; ++e) {
       const int c = 4 * lane + 256 * j + e;
       if (c < C) {
-        red[(0 * 4 + w) * C + c] = acc_g[j][e];
-        red[(1 * 4 + w) * C + c] = acc_b[j][e];
-        red[(2 * 4 + w) * C + c] = acc_z[j][e];
+        red[(0 * NW + w) * C + c] = acc_g[j][e];
+        red[(1 * NW + w) * C + c] = acc_b[j][e];
+        red[(2 * NW + w) * C + c] = acc_z[j][e];
       }
     }
   __syncthreads();
   for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
     const int q = i / C, c = i - q * C;
-    const float v = (red[(q * 4 + 0) * C + c] + red[(q * 4 + 1) * C + c]) + (red[(q * 4 + 2) * C + c] + red[(q * 4 + 3) * C + c]);
+    float v = 0.f;
+    for (int ww = 0; ww < NW; ww += 4)                    // fixed order: deterministic
+      v += (red[(q * NW + ww) * C + c] + red[(q * NW + ww + 1) * C + c]) + (red[(q * NW + ww + 2) * C + c] + red[(q * NW + ww + 3) * C + c]);
     a.partials[(size_t)blockIdx.x * 3 * C + i] = v;
   }
 }
@@ -203,8 +207,9 @@ __global__ __launch_bounds__(256) void k_partial_reduce(const float* partials, i
   }
 }
 
+static int gn_bwd_waves(int C) { return (size_t)3 * GN_BWD_WAVES * C * 4 <= 160 * 1024 ? GN_BWD_WAVES : GN_BWD_WAVES / 2; }
 int gn_bwd_blocks(int64_t rows) {
-  int blocks = (int)((rows + 15) / 16);      // ~4 rows per wave
+  int blocks = (int)((rows + GN_BWD_WAVES - 1) / GN_BWD_WAVES);      // one row per wave until the block cap
   if (blocks > GN_BWD_MAX_BLOCKS) blocks = GN_BWD_MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
   return blocks;
@@ -214,14 +219,27 @@ template <int GW>
 static hipError_t gn_bwd_go(hipStream_t s, const GnBwdArgs& a) {
   const int nj = (a.C + 255) / 256;
   const int blocks = gn_bwd_blocks(a.rows);
-  const size_t lds = (size_t)3 * 4 * a.C * sizeof(float);
+  const int nw = gn_bwd_waves(a.C);
+  const size_t lds = (size_t)3 * nw * a.C * sizeof(float);               // 96 KB at C = 512
+  static bool raised[5] = {false, false, false, false, false};           // per (GW, nj) instantiation of this function template
+  auto go = [&](auto kern) -> hipError_t {
+    if (!raised[nj] && lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      raised[nj] = true;
+    }
+    hipLaunchKernelGGL(kern, blocks, 64 * nw, lds, s, a);
+    return hipSuccess;
+  };
+  hipError_t e = hipSuccess;
   switch (nj) {
-    case 1: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 1>), blocks, 256, lds, s, a); break;
-    case 2: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 2>), blocks, 256, lds, s, a); break;
-    case 3: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 3>), blocks, 256, lds, s, a); break;
-    case 4: hipLaunchKernelGGL((k_gn_silu_bwd<GW, 4>), blocks, 256, lds, s, a); break;
+    case 1: e = go(k_gn_silu_bwd<GW, 1>); break;
+    case 2: e = go(k_gn_silu_bwd<GW, 2>); break;
+    case 3: e = go(k_gn_silu_bwd<GW, 3>); break;
+    case 4: e = go(k_gn_silu_bwd<GW, 4>); break;
     default: return hipErrorInvalidValue;
   }
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_partial_reduce, (3 * a.C + 63) / 64, 256, 0, s, a.partials, blocks, a.C, a.dgamma, a.dbeta, a.dbias);
   return hipGetLastError();
 }
