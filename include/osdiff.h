@@ -143,6 +143,18 @@ int osd_train_loss_fwd_bwd(osd_handle *h, const float *x0, const float *cond, in
                            uint64_t seed, int64_t row_offset, int flags, float *loss_out,
                            float *const *grads, double loss_scale, void *const *events, int n_events);
 
+/* The same network split at the loss, for losses other than the eps-MSE (config.yaml:47 names l1 / huber):
+ * osd_denoiser_forward_train is osd_denoiser_forward with per-row t_index that keeps the activations in the
+ * handle's training workspace (valid until the next training call on the handle); osd_denoiser_backward takes an
+ * arbitrary upstream gradient dout[n][D] = dL/d eps and writes every parameter gradient (overwritten) and, when
+ * dx_t != NULL, dL/dx_t [n][D].  x_t, t_index, cond, masks / seed / row_offset and flags must be the forward call's. */
+int osd_denoiser_forward_train(osd_handle *h, const float *x_t, const int32_t *t_index, const float *cond,
+                               int64_t n, const float *const *masks, uint64_t seed, int64_t row_offset,
+                               int flags, float *eps_out);
+int osd_denoiser_backward(osd_handle *h, const float *x_t, const int32_t *t_index, const float *cond, int64_t n,
+                          const float *dout, const float *const *masks, uint64_t seed, int64_t row_offset,
+                          int flags, float *const *grads, float *dx_t, void *const *events, int n_events);
+
 /* Gradient buckets in the order backward finalises them: bucket b covers parameters
  * [first, last] (indices in named_parameters() order).  Returns the bucket count. */
 int osd_grad_buckets(const osd_config *cfg, int32_t *first, int32_t *last, int max_buckets);

@@ -52,6 +52,9 @@ _SIGNATURES = {
     "osd_sample_chain": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_uint64, C.c_int64, _P, _P, C.c_int]),
     "osd_train_loss_fwd_bwd": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, C.POINTER(_P), C.c_uint64, C.c_int64, C.c_int,
                                          _P, C.POINTER(_P), C.c_double, C.POINTER(_P), C.c_int]),
+    "osd_denoiser_forward_train": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.POINTER(_P), C.c_uint64, C.c_int64, C.c_int, _P]),
+    "osd_denoiser_backward": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.POINTER(_P), C.c_uint64, C.c_int64, C.c_int, C.POINTER(_P), _P,
+                                        C.POINTER(_P), C.c_int]),
     "osd_grad_buckets": (C.c_int, [C.POINTER(OsdConfig), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]),
     "osd_mixup": (C.c_int, [_P, _P, _P, _P, _P, C.c_double, C.c_int64, _P, _P, _P]),
     "osd_clip_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,

@@ -89,55 +89,11 @@ static hipError_t dgrad(hipStream_t s, const float* w, int ldw, int kin, const f
   return launch_linear(s, g, false, true, nullptr, dx, lddx, false, accumulate);
 }
 
-}  // namespace osd
 
-using namespace osd;
-
-extern "C" {
-
-int osd_grad_buckets(const osd_config* cfg, int32_t* first, int32_t* last, int max_buckets) {
-  if (!cfg) return 0;
-  Arch a;
-  if (build_arch(*cfg, &a) != OSD_OK) return 0;
-  // backward finalises: output_proj, then the blocks last-to-first, then everything before the blocks
-  std::vector<std::pair<int, int>> bk;
-  bk.push_back({a.pm.out_w, a.pm.out_b});
-  for (int b = a.n_blocks - 1; b >= 0; --b) bk.push_back({a.layers[2 * b].w, a.layers[2 * b + 1].beta});
-  bk.push_back({0, a.pm.tp_b});
-  const int n = (int)bk.size();
-  if (first && last)
-    for (int i = 0; i < n && i < max_buckets; ++i) { first[i] = bk[i].first; last[i] = bk[i].second; }
-  return n;
-}
-
-int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, int64_t n, const int32_t* t_index, const float* noise,
-                           const float* const* masks, uint64_t seed, int64_t row_offset, int flags, float* loss_out,
-                           float* const* grads, double loss_scale, void* const* events, int n_events) {
-  OSD_TRY(check_ready(h));
-  OSD_TRY(check_rows(n));
-  if (!x0 || !cond || !loss_out) { set_error("null tensor"); return OSD_EINVAL; }
-  if (n == 0) { set_error("empty batch"); return OSD_EINVAL; }
+// sizes (and on growth re-allocates) the training arena for n rows and carves it
+static int ensure_train_ws(osd_handle* h, hipStream_t s, int64_t n, const ConsPlan* cp, TrainWs* w) {
   const Arch& a = h->arch;
-  const ParamMap& pm = a.pm;
-  const int n_buckets = a.n_blocks + 2;
-  if (events && n_events != n_buckets) { set_error("expected %d events (osd_grad_buckets), got %d", n_buckets, n_events); return OSD_EINVAL; }
-  if (grads)
-    for (int i = 0; i < pm.n_params; ++i)
-      if (!grads[i]) { set_error("grads[%d] is null", i); return OSD_EINVAL; }
-  OSD_HIP(hipSetDevice(h->cfg.device));
-  hipStream_t s = h->stream;
-  const bool train = (flags & OSD_F_TRAIN_MODE) != 0;
-  const bool drop = train && h->cfg.dropout_p > 0.f;
-  const int D = a.D;
-  const uint32_t roff = (uint32_t)row_offset;
-
-  const bool use_pw = h->cons.n_pathways > 0 && h->w_pathway != 0.0;
-  const bool use_me = h->cons.n_a > 0 && h->w_mutexpr != 0.0;
-  const ConsPlan* cp = (use_pw || use_me) ? &h->cons : nullptr;
-  if (cp && n < 2) { set_error("the constraint losses need at least 2 rows"); return OSD_EINVAL; }
-  if (!h->parts_dev) OSD_HIP(hipMalloc((void**)&h->parts_dev, 64));
-  TrainWs w;
-  const int64_t need = carve_train(a, nullptr, n, cp, &w);
+  const int64_t need = carve_train(a, nullptr, n, cp, w);
   if (h->train_arena_floats < need) {
     if (h->train_arena) { OSD_HIP(hipStreamSynchronize(s)); OSD_HIP(hipFree(h->train_arena)); h->train_arena = nullptr; h->train_arena_floats = 0; }
     void* p = nullptr;
@@ -145,75 +101,46 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
     h->train_arena = (float*)p;
     h->train_arena_floats = need;
   }
-  carve_train(a, h->train_arena, n, cp, &w);
+  carve_train(a, h->train_arena, n, cp, w);
+  return OSD_OK;
+}
 
-  // ---- zero everything that is accumulated atomically ----
-  {
-    ZeroList zl{};
-    auto add = [&](float* p, int64_t c) { zl.ptr[zl.n] = p; zl.count[zl.n] = c; ++zl.n; };
-    add(loss_out, 1);
-    if (cp) add(h->parts_dev, 3);
-    if (cp && grads) add(w.g_x0, n * (int64_t)D);
-    if (grads) {
-      add(w.g_temb, (int64_t)a.T * a.H0);
-      const int small[] = {pm.ce0_b, pm.ce2_b, pm.in_b, pm.cp_b, pm.tp_b, pm.out_b};
-      for (int i : small) add(grads[i], pm.numel[i]);
-    }
-    if (zl.n > 128) { set_error("too many parameter tensors"); return OSD_EUNSUPPORTED; }
-    OSD_HIP(launch_zero_many(s, zl));
-  }
+// ConditionalEmbedding + cond_proj with the pre-activation kept for backward (models/diffusion.py:101-105, 226)
+static int cond_embed_fwd(osd_handle* h, hipStream_t s, const float* cond, int64_t n, TrainWs& w) {
+  const Arch& a = h->arch;
+  const ParamMap& pm = a.pm;
+  GemmArgs g{};
+  g.A = h->params[pm.ce0_w]; g.lda = a.cond_dim; g.B0 = cond; g.ldb0 = a.cond_dim; g.K0 = a.cond_dim; g.F = 64; g.P = (int)n; g.K = a.cond_dim;
+  OSD_HIP(launch_linear(s, g, true, true, h->params[pm.ce0_b], w.u0, 64, false, false));
+  OSD_HIP(launch_silu_fwd(s, w.u0, w.f.ce1, n * 64));
+  g.A = h->params[pm.ce2_w]; g.lda = 64; g.B0 = w.f.ce1; g.ldb0 = 64; g.K0 = 64; g.K = 64;
+  OSD_HIP(launch_linear(s, g, true, true, h->params[pm.ce2_b], w.f.ce2, 64, false, false));
+  g.A = h->params[pm.cp_w]; g.B0 = w.f.ce2; g.F = a.H0;
+  OSD_HIP(launch_linear(s, g, true, true, h->params[pm.cp_b], w.f.cproj, a.H0, false, false));
+  return OSD_OK;
+}
 
-  // ---- forward (models/diffusion.py:361-377) ----
-  // the t_emb table and the padded input_proj.weight follow the current parameters
-  OSD_TRY(refresh_derived(h, s));
-  const int* t_idx = t_index;
-  if (!t_idx) { OSD_HIP(launch_randint(s, w.t_idx, n, a.T, seed, roff)); t_idx = w.t_idx; }
-  OSD_HIP(launch_q_sample(s, x0, t_idx, h->d_sqrt_ac, h->d_sqrt_1m, noise, n, D, seed, roff, w.x_t, w.noise));
-  const float* eps_true = noise ? noise : w.noise;
-  // ConditionalEmbedding with the pre-activation kept for backward
-  {
-    GemmArgs g{};
-    g.A = h->params[pm.ce0_w]; g.lda = a.cond_dim; g.B0 = cond; g.ldb0 = a.cond_dim; g.K0 = a.cond_dim; g.F = 64; g.P = (int)n; g.K = a.cond_dim;
-    OSD_HIP(launch_linear(s, g, true, true, h->params[pm.ce0_b], w.u0, 64, false, false));
-    OSD_HIP(launch_silu_fwd(s, w.u0, w.f.ce1, n * 64));
-    g.A = h->params[pm.ce2_w]; g.lda = 64; g.B0 = w.f.ce1; g.ldb0 = 64; g.K0 = 64; g.K = 64;
-    OSD_HIP(launch_linear(s, g, true, true, h->params[pm.ce2_b], w.f.ce2, 64, false, false));
-    g.A = h->params[pm.cp_w]; g.B0 = w.f.ce2; g.F = a.H0;
-    OSD_HIP(launch_linear(s, g, true, true, h->params[pm.cp_b], w.f.cproj, a.H0, false, false));
-  }
-  TrainWs& W = w;
-  TrunkIn in{};
-  in.x = W.x_t; in.ldx = D; in.n = n; in.t_index = t_idx; in.train = train; in.save = grads != nullptr;
-  in.masks = masks; in.seed = seed; in.row_offset = roff; in.drop_step = 0;
-  OSD_TRY(run_trunk(h, s, W.f, in));
+// zeroes what the backward accumulates atomically (time-embedding table gradient, the small bias gradients)
+static void add_backward_zeros(const Arch& a, const TrainWs& w, float* const* grads, ZeroList* zl) {
+  const ParamMap& pm = a.pm;
+  auto add = [&](float* p, int64_t c) { zl->ptr[zl->n] = p; zl->count[zl->n] = c; ++zl->n; };
+  add(w.g_temb, (int64_t)a.T * a.H0);
+  const int small[] = {pm.ce0_b, pm.ce2_b, pm.in_b, pm.cp_b, pm.tp_b, pm.out_b};
+  for (int i : small) add(grads[i], pm.numel[i]);
+}
+
+
+// The backward pass from dL/d eps_hat (d_out [n][D]) to every parameter gradient (and optionally dL/dx_t), over the
+// activations a training-mode forward left in W.
+static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* x_t, const int* t_idx, const float* cond, int64_t n,
+                         const float* d_out, bool train, const float* const* masks, uint64_t seed, uint32_t roff, float* const* grads,
+                         float* dx_t, void* const* events) {
+  const Arch& a = h->arch;
+  const ParamMap& pm = a.pm;
+  const int D = a.D;
+  const bool drop = train && h->cfg.dropout_p > 0.f;
   const int last = a.n_blocks - 1;
   const int Hl = a.block_out[last];
-  {
-    GemmArgs g = output_proj_args(h, W.f, n);
-    EpiMse::Args ea{};
-    ea.bias = h->params[pm.out_b]; ea.noise = eps_true; ea.ldn = D;
-    ea.dout = grads ? W.d_out : nullptr; ea.ldd = D; ea.pred = cp ? W.pred : nullptr; ea.ldp = D; ea.loss = loss_out;
-    ea.inv_count = (float)(1.0 / ((double)n * (double)D));
-    ea.gscale = (float)(2.0 * (double)loss_scale / ((double)n * (double)D));
-    OSD_HIP(launch_mse(s, g, ea));
-  }
-  if (cp) {
-    OSD_HIP(hipMemcpyAsync(h->parts_dev, loss_out, 4, hipMemcpyDeviceToDevice, s));
-    // constraint terms on x0_hat (models/diffusion.py:405) against the batch's x0; their gradient joins dL/d eps_hat
-    OSD_HIP(launch_x0hat(s, W.x_t, t_idx, h->d_sqrt_ac, h->d_sqrt_1m, n, D, W.pred));
-    OSD_HIP(hipMemsetAsync(W.cw.acc, 0, (size_t)W.cw.acc_doubles * 8, s));
-    OSD_HIP(cons_moments(s, W.pred, D, n, D, W.cw.acc, W.cw.mi_r));
-    float* gx = grads ? W.g_x0 : nullptr;
-    if (use_pw)
-      OSD_HIP(cons_pathway(s, *cp, W.cw, W.pred, D, n, D, (float)h->w_pathway, (float)(h->w_pathway * loss_scale), loss_out, h->parts_dev + 1, gx));
-    if (use_me) {
-      OSD_HIP(cons_moments(s, x0, D, n, D, W.cw.acc + 2 * (int64_t)D, W.cw.mi_t));
-      OSD_HIP(cons_mutexpr(s, *cp, W.cw, W.pred, x0, D, n, D, (float)h->w_mutexpr, (float)(h->w_mutexpr * loss_scale), loss_out, h->parts_dev + 2, gx));
-    }
-    if (grads) OSD_HIP(launch_x0hat_bwd(s, W.g_x0, t_idx, h->d_sqrt_ac, h->d_sqrt_1m, n, D, W.d_out));
-  }
-  if (!grads) return OSD_OK;
-
   // ---- backward ----
   // Two streams: the chain  GroupNorm/SiLU backward -> dgrad -> next layer  is the critical path and stays on the
   // handle's stream; every weight/bias gradient (wgrad, split-K slab sums, column sums) is a leaf and goes to a
@@ -254,10 +181,10 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   };
   // output_proj
   OSD_TRY(fork());
-  OSD_HIP(wgrad(s2, W, W.f.out[last], Hl, Hl, W.d_out, D, D, n, grads[pm.out_w], Hl));
-  OSD_HIP(launch_colsum(s2, W.d_out, D, n, D, grads[pm.out_b]));
+  OSD_HIP(wgrad(s2, W, W.f.out[last], Hl, Hl, d_out, D, D, n, grads[pm.out_w], Hl));
+  OSD_HIP(launch_colsum(s2, d_out, D, n, D, grads[pm.out_b]));
   OSD_TRY(record());
-  OSD_HIP(dgrad(s, h->params[pm.out_w], Hl, Hl, W.d_out, D, D, n, W.g_out[last], Hl, false));
+  OSD_HIP(dgrad(s, h->params[pm.out_w], Hl, Hl, d_out, D, D, n, W.g_out[last], Hl, false));
 
   const float keep_scale = (float)(1.0 / (1.0 - (double)h->cfg.dropout_p));
   for (int b = a.n_blocks - 1; b >= 0; --b) {
@@ -300,7 +227,8 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   }
   // input_proj, time_proj, cond_proj, ConditionalEmbedding  (h0 = x W^T + b + t_emb[t] + c_proj)
   OSD_TRY(fork());
-  OSD_HIP(wgrad(s2, W, W.x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D));
+  if (dx_t) OSD_HIP(dgrad(s, h->params[pm.in_w], D, D, W.g_h0, a.H0, a.H0, n, dx_t, D, false));
+  OSD_HIP(wgrad(s2, W, x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D));
   OSD_HIP(wgrad(s2, W, W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64));
   OSD_HIP(launch_colsum(s2, W.g_h0, a.H0, n, a.H0, grads[pm.in_b]));
   OSD_HIP(hipMemcpyAsync(grads[pm.cp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s2));
@@ -323,6 +251,159 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
     OSD_HIP(hipEventRecord(e, s2));
     OSD_HIP(hipStreamWaitEvent(s, e, 0));
   }
+  return OSD_OK;
+}
+
+}  // namespace osd
+
+using namespace osd;
+
+extern "C" {
+
+int osd_grad_buckets(const osd_config* cfg, int32_t* first, int32_t* last, int max_buckets) {
+  if (!cfg) return 0;
+  Arch a;
+  if (build_arch(*cfg, &a) != OSD_OK) return 0;
+  // backward finalises: output_proj, then the blocks last-to-first, then everything before the blocks
+  std::vector<std::pair<int, int>> bk;
+  bk.push_back({a.pm.out_w, a.pm.out_b});
+  for (int b = a.n_blocks - 1; b >= 0; --b) bk.push_back({a.layers[2 * b].w, a.layers[2 * b + 1].beta});
+  bk.push_back({0, a.pm.tp_b});
+  const int n = (int)bk.size();
+  if (first && last)
+    for (int i = 0; i < n && i < max_buckets; ++i) { first[i] = bk[i].first; last[i] = bk[i].second; }
+  return n;
+}
+
+int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, int64_t n, const int32_t* t_index, const float* noise,
+                           const float* const* masks, uint64_t seed, int64_t row_offset, int flags, float* loss_out,
+                           float* const* grads, double loss_scale, void* const* events, int n_events) {
+  OSD_TRY(check_ready(h));
+  OSD_TRY(check_rows(n));
+  if (!x0 || !cond || !loss_out) { set_error("null tensor"); return OSD_EINVAL; }
+  if (n == 0) { set_error("empty batch"); return OSD_EINVAL; }
+  const Arch& a = h->arch;
+  const ParamMap& pm = a.pm;
+  const int n_buckets = a.n_blocks + 2;
+  if (events && n_events != n_buckets) { set_error("expected %d events (osd_grad_buckets), got %d", n_buckets, n_events); return OSD_EINVAL; }
+  if (grads)
+    for (int i = 0; i < pm.n_params; ++i)
+      if (!grads[i]) { set_error("grads[%d] is null", i); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  hipStream_t s = h->stream;
+  const bool train = (flags & OSD_F_TRAIN_MODE) != 0;
+  const int D = a.D;
+  const uint32_t roff = (uint32_t)row_offset;
+
+  const bool use_pw = h->cons.n_pathways > 0 && h->w_pathway != 0.0;
+  const bool use_me = h->cons.n_a > 0 && h->w_mutexpr != 0.0;
+  const ConsPlan* cp = (use_pw || use_me) ? &h->cons : nullptr;
+  if (cp && n < 2) { set_error("the constraint losses need at least 2 rows"); return OSD_EINVAL; }
+  if (!h->parts_dev) OSD_HIP(hipMalloc((void**)&h->parts_dev, 64));
+  TrainWs w;
+  OSD_TRY(ensure_train_ws(h, s, n, cp, &w));
+  h->saved_rows = -1;                    // the workspace no longer matches an osd_denoiser_forward_train call
+
+  // ---- zero everything that is accumulated atomically ----
+  {
+    ZeroList zl{};
+    auto add = [&](float* p, int64_t c) { zl.ptr[zl.n] = p; zl.count[zl.n] = c; ++zl.n; };
+    add(loss_out, 1);
+    if (cp) add(h->parts_dev, 3);
+    if (cp && grads) add(w.g_x0, n * (int64_t)D);
+    if (grads) add_backward_zeros(a, w, grads, &zl);
+    if (zl.n > 128) { set_error("too many parameter tensors"); return OSD_EUNSUPPORTED; }
+    OSD_HIP(launch_zero_many(s, zl));
+  }
+
+  // ---- forward (models/diffusion.py:361-377) ----
+  // the t_emb table and the padded input_proj.weight follow the current parameters
+  OSD_TRY(refresh_derived(h, s));
+  const int* t_idx = t_index;
+  if (!t_idx) { OSD_HIP(launch_randint(s, w.t_idx, n, a.T, seed, roff)); t_idx = w.t_idx; }
+  OSD_HIP(launch_q_sample(s, x0, t_idx, h->d_sqrt_ac, h->d_sqrt_1m, noise, n, D, seed, roff, w.x_t, w.noise));
+  const float* eps_true = noise ? noise : w.noise;
+  OSD_TRY(cond_embed_fwd(h, s, cond, n, w));
+  TrainWs& W = w;
+  TrunkIn in{};
+  in.x = W.x_t; in.ldx = D; in.n = n; in.t_index = t_idx; in.train = train; in.save = grads != nullptr;
+  in.masks = masks; in.seed = seed; in.row_offset = roff; in.drop_step = 0;
+  OSD_TRY(run_trunk(h, s, W.f, in));
+  {
+    GemmArgs g = output_proj_args(h, W.f, n);
+    EpiMse::Args ea{};
+    ea.bias = h->params[pm.out_b]; ea.noise = eps_true; ea.ldn = D;
+    ea.dout = grads ? W.d_out : nullptr; ea.ldd = D; ea.pred = cp ? W.pred : nullptr; ea.ldp = D; ea.loss = loss_out;
+    ea.inv_count = (float)(1.0 / ((double)n * (double)D));
+    ea.gscale = (float)(2.0 * (double)loss_scale / ((double)n * (double)D));
+    OSD_HIP(launch_mse(s, g, ea));
+  }
+  if (cp) {
+    OSD_HIP(hipMemcpyAsync(h->parts_dev, loss_out, 4, hipMemcpyDeviceToDevice, s));
+    // constraint terms on x0_hat (models/diffusion.py:405) against the batch's x0; their gradient joins dL/d eps_hat
+    OSD_HIP(launch_x0hat(s, W.x_t, t_idx, h->d_sqrt_ac, h->d_sqrt_1m, n, D, W.pred));
+    OSD_HIP(hipMemsetAsync(W.cw.acc, 0, (size_t)W.cw.acc_doubles * 8, s));
+    OSD_HIP(cons_moments(s, W.pred, D, n, D, W.cw.acc, W.cw.mi_r));
+    float* gx = grads ? W.g_x0 : nullptr;
+    if (use_pw)
+      OSD_HIP(cons_pathway(s, *cp, W.cw, W.pred, D, n, D, (float)h->w_pathway, (float)(h->w_pathway * loss_scale), loss_out, h->parts_dev + 1, gx));
+    if (use_me) {
+      OSD_HIP(cons_moments(s, x0, D, n, D, W.cw.acc + 2 * (int64_t)D, W.cw.mi_t));
+      OSD_HIP(cons_mutexpr(s, *cp, W.cw, W.pred, x0, D, n, D, (float)h->w_mutexpr, (float)(h->w_mutexpr * loss_scale), loss_out, h->parts_dev + 2, gx));
+    }
+    if (grads) OSD_HIP(launch_x0hat_bwd(s, W.g_x0, t_idx, h->d_sqrt_ac, h->d_sqrt_1m, n, D, W.d_out));
+  }
+  if (!grads) return OSD_OK;
+
+  OSD_TRY(backward_from(h, s, W, W.x_t, t_idx, cond, n, W.d_out, train, masks, seed, roff, grads, nullptr, events));
+  if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
+  return OSD_OK;
+}
+
+int osd_denoiser_forward_train(osd_handle* h, const float* x_t, const int32_t* t_index, const float* cond, int64_t n,
+                               const float* const* masks, uint64_t seed, int64_t row_offset, int flags, float* eps_out) {
+  OSD_TRY(check_ready(h));
+  OSD_TRY(check_rows(n));
+  if (!x_t || !t_index || !cond || !eps_out || n == 0) { set_error("null tensor or empty batch"); return OSD_EINVAL; }
+  const Arch& a = h->arch;
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  hipStream_t s = h->stream;
+  TrainWs W;
+  OSD_TRY(ensure_train_ws(h, s, n, nullptr, &W));
+  h->saved_rows = -1;
+  OSD_TRY(refresh_derived(h, s));
+  OSD_TRY(cond_embed_fwd(h, s, cond, n, W));
+  TrunkIn in{};
+  in.x = x_t; in.ldx = a.D; in.n = n; in.t_index = t_index; in.train = (flags & OSD_F_TRAIN_MODE) != 0; in.save = true;
+  in.masks = masks; in.seed = seed; in.row_offset = (uint32_t)row_offset; in.drop_step = 0;
+  OSD_TRY(run_trunk(h, s, W.f, in));
+  GemmArgs g = output_proj_args(h, W.f, n);
+  OSD_HIP(launch_linear(s, g, true, true, h->params[a.pm.out_b], eps_out, a.D, false, false));
+  h->saved_rows = n;
+  if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
+  return OSD_OK;
+}
+
+int osd_denoiser_backward(osd_handle* h, const float* x_t, const int32_t* t_index, const float* cond, int64_t n, const float* dout,
+                          const float* const* masks, uint64_t seed, int64_t row_offset, int flags, float* const* grads, float* dx_t,
+                          void* const* events, int n_events) {
+  OSD_TRY(check_ready(h));
+  OSD_TRY(check_rows(n));
+  if (!x_t || !t_index || !cond || !dout || !grads || n == 0) { set_error("null tensor or empty batch"); return OSD_EINVAL; }
+  if (h->saved_rows != n) { set_error("osd_denoiser_backward needs the activations of an osd_denoiser_forward_train call on the same %lld rows", (long long)n); return OSD_ESTATE; }
+  const Arch& a = h->arch;
+  const int n_buckets = a.n_blocks + 2;
+  if (events && n_events != n_buckets) { set_error("expected %d events (osd_grad_buckets), got %d", n_buckets, n_events); return OSD_EINVAL; }
+  for (int i = 0; i < a.pm.n_params; ++i)
+    if (!grads[i]) { set_error("grads[%d] is null", i); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(h->cfg.device));
+  hipStream_t s = h->stream;
+  TrainWs W;
+  carve_train(a, h->train_arena, n, nullptr, &W);       // same carving as the forward call: pointers to its activations
+  ZeroList zl{};
+  add_backward_zeros(a, W, grads, &zl);
+  OSD_HIP(launch_zero_many(s, zl));
+  OSD_TRY(backward_from(h, s, W, x_t, t_index, cond, n, dout, (flags & OSD_F_TRAIN_MODE) != 0, masks, seed, (uint32_t)row_offset, grads, dx_t, events));
   if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
   return OSD_OK;
 }

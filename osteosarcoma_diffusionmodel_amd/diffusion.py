@@ -145,6 +145,7 @@ class _Engine:
         L.check(lib.osd_set_schedule(self.handle, L.ptr(sa), L.ptr(s1), L.ptr(coef.contiguous()), L.ptr(temb)))
         self._sig = None
         self.constraints_version = 0
+        self.serial = 0                 # bumped by every call that rewrites the handle's training workspace
 
     def set_constraints(self, spec):
         lib = L.lib()
@@ -389,6 +390,12 @@ class BiologyAwareDiffusionModel(nn.Module):
             keep = [self._prep(m, name="dropout mask") for m in dropout_masks]
             masks = L.ptr_array(keep)
         seed = _draw_seed() if seed is None else seed
+        if torch.is_grad_enabled() and (x_t.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # differentiable path (custom losses): activations kept for osd_denoiser_backward
+            from .train import denoiser_with_grad
+            if t_idx is None:
+                t_idx = torch.full((n,), t_all, device=x_t.device, dtype=torch.int32)
+            return denoiser_with_grad(self, x_t, t_idx, conditions, keep if dropout_masks is not None else None, seed, flags)
         L.check(L.lib().osd_denoiser_forward(eng.handle, L.ptr(x_t), L.ptr(t_idx), t_all, L.ptr(conditions), n,
                                              L.ptr(eps), flags, masks, seed))
         return eps

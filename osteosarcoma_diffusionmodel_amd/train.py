@@ -94,6 +94,7 @@ def _loss_fwd_bwd(model: BiologyAwareDiffusionModel, x0, cond, grad_ptrs, *, t=N
         n_ev = len(events)
     L.check(L.lib().osd_train_loss_fwd_bwd(eng.handle, L.ptr(x0), L.ptr(cond), n, L.ptr(t32), L.ptr(nz), masks, seed,
                                            int(row_offset), flags, L.ptr(loss), grad_ptrs, float(loss_scale), ev_arr, n_ev))
+    eng.serial += 1           # the training workspace now belongs to this call
     return loss
 
 
@@ -117,6 +118,48 @@ class _DiffusionLoss(torch.autograd.Function):
         if ctx.grads is None:
             return (None,) * 7
         return (None,) * 7 + tuple(g * gout for g in ctx.grads)
+
+
+class _DenoiserFn(torch.autograd.Function):
+    """eps_hat = unet(x_t, t/T, embed(c)) as a differentiable op for losses other than the built-in eps-MSE:
+    osd_denoiser_forward_train keeps the activations in the handle's workspace, osd_denoiser_backward turns the
+    upstream dL/d eps_hat into every parameter gradient (and dL/dx_t when x_t requires grad).  Only the most recent
+    training-mode forward of a model can be back-propagated (one workspace per handle)."""
+
+    @staticmethod
+    def forward(ctx, model, x_t, t32, cond, keep, seed, flags, *params):
+        eng = model._engine()
+        n = x_t.shape[0]
+        eps = torch.empty_like(x_t)
+        masks = L.ptr_array(keep) if keep is not None else None
+        L.check(L.lib().osd_denoiser_forward_train(eng.handle, L.ptr(x_t), L.ptr(t32), L.ptr(cond), n, masks, seed, 0, flags, L.ptr(eps)))
+        eng.serial += 1
+        ctx.model, ctx.keep, ctx.cfg = model, keep, (seed, flags, eng.serial)
+        ctx.save_for_backward(x_t, t32, cond)
+        ctx.n_params = len(params)
+        return eps
+
+    @staticmethod
+    def backward(ctx, g_eps):
+        x_t, t32, cond = ctx.saved_tensors
+        seed, flags, serial = ctx.cfg
+        model = ctx.model
+        eng = model._engine()
+        if eng.serial != serial:
+            raise RuntimeError("the activations of this predict_noise call were overwritten by a later training-mode forward of the "
+                               "same model; call backward() before the next forward")
+        params = model._param_list()
+        grads = [torch.empty_like(p) for p in params]
+        dx = torch.empty_like(x_t) if ctx.needs_input_grad[1] else None
+        g = g_eps.to(torch.float32).contiguous()
+        masks = L.ptr_array(ctx.keep) if ctx.keep is not None else None
+        L.check(L.lib().osd_denoiser_backward(eng.handle, L.ptr(x_t), L.ptr(t32), L.ptr(cond), x_t.shape[0], L.ptr(g), masks, seed, 0, flags,
+                                              L.ptr_array(grads), L.ptr(dx), None, 0))
+        return (None, dx, None, None, None, None, None) + tuple(grads)
+
+
+def denoiser_with_grad(model: BiologyAwareDiffusionModel, x_t, t32, cond, keep, seed, flags):
+    return _DenoiserFn.apply(model, x_t, t32, cond, keep, seed, flags, *model._param_list())
 
 
 def diffusion_loss(model: BiologyAwareDiffusionModel, x_0, conditions, *, t=None, noise=None, dropout_masks=None, seed=None):

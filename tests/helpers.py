@@ -38,14 +38,20 @@ def small_model(golden_dir, T=1000, p=0.2, device="cuda"):
 
 
 def rel_err(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, dtype=np.float64)
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+def _np64(v):
+    if isinstance(v, torch.Tensor):
+        v = v.detach().cpu()
+    return np.asarray(v, dtype=np.float64)
+
+
 def assert_close(a, b, rtol, atol=0.0, what=""):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    a = _np64(a)
+    b = _np64(b)
     assert a.shape == b.shape, (a.shape, b.shape)
     tol = atol + rtol * np.abs(b).max()
     err = np.abs(a - b).max()

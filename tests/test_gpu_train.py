@@ -246,3 +246,46 @@ def test_trainer_full_loop_runs(golden_dir, tmp_path):
     assert list(ck["model_state_dict"]) == list(m.state_dict())
     assert (tmp_path / "checkpoint_epoch_0.pt").exists()
     assert hist["train_loss"][-1] < hist["train_loss"][0] + 0.5
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_custom_loss_through_differentiable_predict_noise(golden_dir, mode):
+    """osd_denoiser_forward_train + osd_denoiser_backward: a Huber loss on eps_hat (config.yaml:47 lists l1 / l2 / huber)
+    back-propagated to every parameter and to x_t, against autograd over the oracle."""
+    g = load_golden(golden_dir, "g3g4_small_model")
+    sd = golden_small_sd(golden_dir)
+    params = {k: v for k, v in sd.items() if k.startswith(("condition_embed", "unet"))}
+    m = small_model(golden_dir)
+    gen = torch.Generator().manual_seed(3)
+    rows = 37
+    x_t = torch.randn(rows, 40, generator=gen)
+    cond = torch.randn(rows, 3, generator=gen)
+    t = torch.randint(0, 1000, (rows,), generator=gen)
+    target = torch.randn(rows, 40, generator=gen)
+    masks = None
+    if mode == "train":
+        m.train()
+        masks = [(torch.rand(rows, c, generator=gen) > 0.2).float() for c in (SM_H[1], SM_H[2], SM_H[2], SM_H[1], SM_H[0])]
+    # oracle
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo = x_t.clone().requires_grad_(True)
+    pred = O.unet_forward(leaves, xo, t.float() / 1000, O.condition_embed(leaves, cond), len(SM_H), 128, masks, 0.2 if masks else 0.0)
+    ref = torch.nn.functional.smooth_l1_loss(pred, target)
+    gref = torch.autograd.grad(ref, [xo] + list(leaves.values()))
+    # device
+    xd = x_t.cuda().requires_grad_(True)
+    eps = m.predict_noise(xd, t.cuda(), cond.cuda(), dropout_masks=[k.cuda() for k in masks] if masks else None)
+    assert eps.requires_grad
+    loss = torch.nn.functional.smooth_l1_loss(eps, target.cuda())
+    loss.backward()
+    assert_close(eps.detach().cpu(), pred.detach(), 1e-5, what="eps_hat")
+    assert_close(loss.item(), ref.item(), 1e-5, what="huber loss")
+    assert_close(xd.grad.cpu(), gref[0], GRAD_RTOL, atol=1e-9, what="dL/dx_t")
+    named = dict(m.named_parameters())
+    for k, gr in zip(leaves, gref[1:]):
+        assert_close(named[k].grad.cpu(), gr, GRAD_RTOL, atol=1e-9, what=f"grad {k}")
+    # a second forward invalidates the first one's workspace: its backward must refuse, not compute garbage
+    e1 = m.predict_noise(xd, t.cuda(), cond.cuda(), dropout_masks=[k.cuda() for k in masks] if masks else None)
+    m.predict_noise(xd, t.cuda(), cond.cuda(), dropout_masks=[k.cuda() for k in masks] if masks else None)
+    with pytest.raises(RuntimeError):
+        e1.sum().backward()

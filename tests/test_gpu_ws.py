@@ -41,12 +41,13 @@ def test_single_step_and_eager_forward_bitwise_equal():
     x = torch.randn(rows, 2000, device="cuda")
     cond = torch.randn(rows, 3, device="cuda")
     try:
-        _set_ws(m, 0)
-        a = m.predict_noise(x, 500, cond)
-        pa = m.p_sample(x, 500, cond, seed=5)
-        _set_ws(m, 1)
-        b = m.predict_noise(x, 500, cond)
-        pb = m.p_sample(x, 500, cond, seed=5)
+        with torch.no_grad():
+            _set_ws(m, 0)
+            a = m.predict_noise(x, 500, cond)
+            pa = m.p_sample(x, 500, cond, seed=5)
+            _set_ws(m, 1)
+            b = m.predict_noise(x, 500, cond)
+            pb = m.p_sample(x, 500, cond, seed=5)
     finally:
         _set_ws(m, 0)
     assert torch.equal(a, b) and torch.equal(pa, pb)
