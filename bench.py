@@ -181,11 +181,12 @@ def main():
         roof = {"bound": "mfma", "kernel": "gemm_glds_kernel<Tile<128,128,64,64>, EpiGnSilu<64>> (Linear+GroupNorm+SiLU, 512-wide layers)",
                 "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_gbps": None if traffic is None else round(traffic / (dom_ms * 1e-3) / 1e9, 1),
                 "avg_launch_ms": round(dom_ms, 4), "rows_per_launch": rows,
                 "whole_step": {"ms": round(step_ms, 3),
                                "tflops": round(rows * FLOP_PER_PATIENT_STEP / (step_ms * 1e-3) / 1e12, 2)},
                 "launches": launches}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (one host, one CPU timing)
             cpu = cpu_baseline(model.state_dict())
 
     if rank == 0:
