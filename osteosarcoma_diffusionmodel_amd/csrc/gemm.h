@@ -39,7 +39,6 @@ struct GemmArgs {
   int kchunk;                  // gemm_kernel split-K: blockIdx.y reduces k in [y*kchunk, (y+1)*kchunk); 0 = no split
   int persist;                 // gemm_glds_kernel: persistent patient-tile walk (see gemm_glds.h)
   unsigned long long* stamps;  // diagnostic: per-wave s_memtime stamps [wave][4] (null in production)
-  int stagger;                 // gemm_glds_kernel: start delay (units of 64 cycles) of the second co-resident workgroup
 };
 
 template <int BF_, int BP_, int WF_, int WP_>
