@@ -294,3 +294,45 @@ def test_million_patient_scale_and_row_addressing():
     for off, cnt in ((0, 257), (654_321, 1000), (n - 129, 129)):
         xs, ms = m.sample(cond[off:off + cnt].contiguous(), cnt, seed=99, row_offset=off, return_mutation_mask=True)
         assert torch.equal(xs, x[off:off + cnt]) and torch.equal(ms, mask[off:off + cnt])
+
+
+def test_chain_with_trained_weights_vs_oracle(golden_dir):
+    """parity with a briefly trained checkpoint -- the oracle trains the small model on CPU for 150
+    AdamW steps on structured synthetic data, then the device runs the T = 200 reverse chain with the trained weights and
+    the oracle's noise (the un-clamped x0_hat of the reference still amplifies the first steps: |x| reaches ~4e4, two
+    orders below the random-weight chains); the mutation mask must match bit for bit away from the threshold."""
+    T, rows, D = 200, 48, 40
+    sd = {k: v.clone() for k, v in golden_small_sd(golden_dir).items() if k.startswith(("condition_embed", "unet"))}
+    bufs = O.schedule_buffers("cosine", T)
+    gen = torch.Generator().manual_seed(123)
+    basis = torch.randn(4, D, generator=gen)
+    def batch(n):
+        x0 = torch.randn(n, 4, generator=gen) @ basis * 0.5 + 0.1 * torch.randn(n, D, generator=gen)
+        x0[:, :8] = (x0[:, :8] > 0).float()
+        return x0, torch.randn(n, 3, generator=gen)
+    names = list(sd)
+    m1 = [torch.zeros_like(sd[k]) for k in names]
+    m2 = [torch.zeros_like(sd[k]) for k in names]
+    first = last = None
+    for step in range(1, 151):
+        x0, c = batch(64)
+        t = torch.randint(0, T, (64,), generator=gen)
+        nz = torch.randn(64, D, generator=gen)
+        loss, grads = O.training_loss_and_grads(sd, bufs, x0, c, t, nz, len(SM_H), 128)
+        gl, _ = O.clip_grad_norm([grads[k] for k in names], 1.0)
+        O.adamw_step([sd[k] for k in names], gl, m1, m2, step, lr=2e-3, weight_decay=1e-5)
+        first = loss.item() if first is None else first
+        last = loss.item()
+    assert last < 0.9 * first                                    # it learned something
+    cond = torch.randn(rows, 3, generator=gen)
+    x_T = torch.randn(rows, D, generator=gen)
+    zs = torch.randn(T - 1, rows, D, generator=gen)              # draw order t = T-1 .. 1
+    ref = O.sample(sd, bufs, cond, x_T, lambda t: zs[T - 1 - t], len(SM_H), 128)
+    m = BiologyAwareDiffusionModel(config=config(SM_H, T=T), **SM)
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda().eval()
+    out, mask = m.sample(cond.cuda(), rows, x_T=x_T.cuda(), noise=zs.cuda(), return_mutation_mask=True)
+    assert_close(out, ref, CHAIN_RTOL, atol=1e-5, what="trained-weights chain")
+    refm = (ref[:, :8] > 0.5).float()
+    near = (ref[:, :8] - 0.5).abs() <= CHAIN_RTOL * ref.abs().max()
+    assert ((mask.cpu() != refm) & ~near).sum().item() == 0
