@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Secondary metric (BASELINE config 2): diffusion training samples/s at B=4096, D=2000 on one GPU
-(mixup + fused fwd/bwd + clip + AdamW per step), with the CPU oracle's step timed beside it."""
+(mixup + fused fwd/bwd + clip + AdamW per step)."""
 import sys
 import time
 from pathlib import Path
