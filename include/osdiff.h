@@ -21,6 +21,12 @@
  *   - all work is enqueued on the handle's stream (osd_set_stream) and is
  *     asynchronous unless stated; calls on one handle are not re-entrant.
  *   - no CPU fallback exists: without a HIP device every compute call fails.
+ *   - row_offset (global id of the call's first row) addresses the Philox stream with
+ *     32-bit row counters: row_offset < 0 or row_offset + n > 2^32 is OSD_EINVAL.
+ *   - t_index entries must lie in [0, T): the reference's buffer gather raises
+ *     IndexError otherwise (models/diffusion.py:337) and so does the Python shim; the
+ *     library itself cannot see device values without a sync, so it clamps a
+ *     caller-supplied t_index into [0, T) (no out-of-bounds table read can occur).
  */
 #ifndef OSDIFF_H
 #define OSDIFF_H
@@ -158,6 +164,27 @@ int osd_denoiser_backward(osd_handle *h, const float *x_t, const int32_t *t_inde
 /* Gradient buckets in the order backward finalises them: bucket b covers parameters
  * [first, last] (indices in named_parameters() order).  Returns the bucket count. */
 int osd_grad_buckets(const osd_config *cfg, int32_t *first, int32_t *last, int max_buckets);
+
+/* ---- data-parallel gradient exchange over RCCL / xGMI ------------------------------
+ * The reference is single-process; the slot these fill is between loss.backward() and clip_grad_norm_
+ * (utils/train.py:239-244).  One communicator per process (one process per GPU).  RCCL is bound at run time
+ * (dlopen): OSD_EUNSUPPORTED when no librccl.so can be found.
+ *   osd_comm_unique_id   rank 0 draws the 128-byte rendezvous id (ncclGetUniqueId); the caller ships it to the
+ *                        other ranks (the Python shim broadcasts it through torch.distributed's store)
+ *   osd_comm_create      collective over all ranks (ncclCommInitRank) on HIP device `device`
+ *   osd_allreduce_grads_begin  SUM all-reduce of flat_grad[start[b], end[b]) (element offsets) for b = 0..n_buckets-1
+ *                        on the communicator's stream; bucket b waits for events[b] (the hipEvent_t array handed
+ *                        to osd_train_loss_fwd_bwd), or -- events == NULL -- for everything queued on the
+ *                        handle's stream.  Gradients are pre-scaled by 1/world through loss_scale.
+ *   osd_allreduce_grads_end    the handle's stream waits for the collectives (then clip + AdamW may run) */
+#define OSD_COMM_ID_BYTES 128
+typedef struct osd_comm osd_comm;
+int osd_comm_unique_id(void *id_out128);
+int osd_comm_create(const void *id128, int rank, int world, int device, osd_comm **out);
+int osd_comm_destroy(osd_comm *c);
+int osd_allreduce_grads_begin(osd_handle *h, osd_comm *c, float *flat_grad, const int64_t *start,
+                              const int64_t *end, void *const *events, int n_buckets);
+int osd_allreduce_grads_end(osd_handle *h, osd_comm *c);
 
 /* MixupAugmentation.__call__ (utils/train.py:108-120): out = lam*v + (1-lam)*v[perm]
  * for data[n][D], conditions[n][cond_dim], survival[n]; perm dev int64[n]. */

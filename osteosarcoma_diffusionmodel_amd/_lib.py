@@ -12,6 +12,7 @@ from pathlib import Path
 OSD_MAX_HIDDEN = 8
 OSD_F_GRAPH, OSD_F_TRAIN_MODE, OSD_F_SYNC = 1, 2, 4
 OSD_OK, OSD_EINVAL, OSD_ENOMEM, OSD_EHIP, OSD_ESTATE, OSD_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+OSD_COMM_ID_BYTES = 128
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libosdiff.so"
 
@@ -56,6 +57,11 @@ _SIGNATURES = {
     "osd_denoiser_backward": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.POINTER(_P), C.c_uint64, C.c_int64, C.c_int, C.POINTER(_P), _P,
                                         C.POINTER(_P), C.c_int]),
     "osd_grad_buckets": (C.c_int, [C.POINTER(OsdConfig), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]),
+    "osd_comm_unique_id": (C.c_int, [_P]),
+    "osd_comm_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "osd_comm_destroy": (C.c_int, [_P]),
+    "osd_allreduce_grads_begin": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(_P), C.c_int]),
+    "osd_allreduce_grads_end": (C.c_int, [_P, _P]),
     "osd_mixup": (C.c_int, [_P, _P, _P, _P, _P, C.c_double, C.c_int64, _P, _P, _P]),
     "osd_clip_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
                                       C.c_double, C.c_double, C.c_int64, _P]),

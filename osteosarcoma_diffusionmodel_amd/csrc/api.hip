@@ -34,24 +34,10 @@ int persist_mode() {
   }
   return mode;
 }
-static int g_ws_mode = -1;
-int ws_mode() {
-  if (g_ws_mode < 0) {
-    const char* e = getenv("OSD_WS");
-    g_ws_mode = e ? atoi(e) : 0;
-  }
-  return g_ws_mode;
-}
-static bool g_ws_available = true;
-bool ws_available() { return g_ws_available; }
 hipError_t prepare_kernels() {
   for (const KernelReg& k : kernel_registry()) {
     hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.lds_bytes);
-    if (e != hipSuccess) {
-      if (!k.optional) return e;
-      g_ws_available = false;          // the 160 KB wave-specialised variant is an optimisation: fall back to gemm_glds_kernel
-      (void)hipGetLastError();
-    }
+    if (e != hipSuccess) return e;
   }
   return hipSuccess;
 }
@@ -261,6 +247,30 @@ int check_rows(int64_t n) {
   return OSD_OK;
 }
 
+// Global row ids address the Philox stream as 32-bit counters: a shard whose ids would wrap would repeat another
+// shard's draws, so it is rejected instead of truncated.
+int check_row_offset(int64_t row_offset, int64_t n) {
+  if (row_offset < 0 || row_offset + n > ((int64_t)1 << 32)) {
+    set_error("row_offset %lld + %lld rows is outside the 32-bit global row id space [0, 2^32)", (long long)row_offset, (long long)n);
+    return OSD_EINVAL;
+  }
+  return OSD_OK;
+}
+
+// Caller-supplied per-row timestep indices, clamped into [0, T) in a handle-owned buffer (see k_clamp_int).
+int sanitize_t(osd_handle* h, hipStream_t s, const int32_t* t_index, int64_t n, const int** out) {
+  if (!t_index) { *out = nullptr; return OSD_OK; }
+  if (h->t_san_cap < n) {
+    if (h->t_san) { OSD_HIP(hipStreamSynchronize(s)); OSD_HIP(hipFree(h->t_san)); h->t_san = nullptr; h->t_san_cap = 0; }
+    const int64_t cap = (n + 1023) / 1024 * 1024;
+    if (hipMalloc((void**)&h->t_san, (size_t)cap * 4) != hipSuccess) { set_error("hipMalloc of %lld bytes failed", (long long)cap * 4); return OSD_ENOMEM; }
+    h->t_san_cap = cap;
+  }
+  OSD_HIP(launch_clamp_int(s, t_index, n, 0, h->arch.T - 1, h->t_san));
+  *out = h->t_san;
+  return OSD_OK;
+}
+
 }  // namespace osd
 
 using namespace osd;
@@ -285,6 +295,23 @@ int64_t osd_param_numel(const osd_config* cfg, int i) {
   return a.pm.numel[i];
 }
 
+static int create_device_state(osd_handle* h) {
+  const Arch& a = h->arch;
+  const int T = a.T;
+  OSD_HIP(hipMalloc((void**)&h->d_sqrt_ac, (size_t)T * 4));
+  OSD_HIP(hipMalloc((void**)&h->d_sqrt_1m, (size_t)T * 4));
+  OSD_HIP(hipMalloc((void**)&h->d_coef, (size_t)T * 4 * 4));
+  OSD_HIP(hipMalloc((void**)&h->d_time_emb, (size_t)T * a.time_dim * 4));
+  OSD_HIP(hipMalloc((void**)&h->d_temb, (size_t)T * a.H0 * 4));
+  h->w_in_ld = (a.D + BK - 1) / BK * BK;
+  OSD_HIP(hipMalloc((void**)&h->w_in_packed, (size_t)a.H0 * h->w_in_ld * 4));
+  OSD_HIP(hipMemset(h->w_in_packed, 0, (size_t)a.H0 * h->w_in_ld * 4));
+  OSD_HIP(hipMalloc((void**)&h->main.t_dev, 64));
+  OSD_HIP(hipMalloc((void**)&h->loss_dev, 64));
+  OSD_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+  return OSD_OK;
+}
+
 int osd_create(const osd_config* cfg, osd_handle** out) {
   if (!cfg || !out) { set_error("null argument"); return OSD_EINVAL; }
   *out = nullptr;
@@ -299,18 +326,11 @@ int osd_create(const osd_config* cfg, osd_handle** out) {
   if (!h) { set_error("out of host memory"); return OSD_ENOMEM; }
   h->cfg = *cfg;
   h->arch = a;
-  const int T = a.T;
-  OSD_HIP(hipMalloc((void**)&h->d_sqrt_ac, T * 4));
-  OSD_HIP(hipMalloc((void**)&h->d_sqrt_1m, T * 4));
-  OSD_HIP(hipMalloc((void**)&h->d_coef, (size_t)T * 4 * 4));
-  OSD_HIP(hipMalloc((void**)&h->d_time_emb, (size_t)T * a.time_dim * 4));
-  OSD_HIP(hipMalloc((void**)&h->d_temb, (size_t)T * a.H0 * 4));
-  h->w_in_ld = (a.D + BK - 1) / BK * BK;
-  OSD_HIP(hipMalloc((void**)&h->w_in_packed, (size_t)a.H0 * h->w_in_ld * 4));
-  OSD_HIP(hipMemset(h->w_in_packed, 0, (size_t)a.H0 * h->w_in_ld * 4));
-  OSD_HIP(hipMalloc((void**)&h->main.t_dev, 64));
-  OSD_HIP(hipMalloc((void**)&h->loss_dev, 64));
-  OSD_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+  const int rc = create_device_state(h);
+  if (rc != OSD_OK) {                 // nothing of a half-built handle survives (osd_destroy frees what was allocated)
+    osd_destroy(h);
+    return rc;
+  }
   *out = h;
   return OSD_OK;
 }
@@ -337,6 +357,7 @@ int osd_destroy(osd_handle* h) {
   for (float* p : bufs) if (p) e = hipFree(p);
   if (h->normsq_dev) e = hipFree(h->normsq_dev);
   if (h->parts_dev) e = hipFree(h->parts_dev);
+  if (h->t_san) e = hipFree(h->t_san);
   for (hipEvent_t ev : h->ev_pool) e = hipEventDestroy(ev);
   if (h->wgrad_stream) e = hipStreamDestroy(h->wgrad_stream);
   cons_free_plan(&h->cons);
@@ -364,11 +385,6 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
     h->n_streams = (int)value;
     return OSD_OK;
   }
-  if (!strcmp(name, "wave_specialized")) {       // process-wide: 0 off, 1 for launches of >= 512 tiles, 2 whenever the 128x128 tile is used
-    if (value < 0 || value > 2) { set_error("wave_specialized must be 0, 1 or 2"); return OSD_EINVAL; }
-    g_ws_mode = (int)value;
-    return OSD_OK;
-  }
   if (!strcmp(name, "train_streams")) {
     if (value < 1 || value > 2) { set_error("train_streams must be 1 or 2"); return OSD_EINVAL; }
     h->two_stream_bwd = value == 2;
@@ -382,8 +398,8 @@ int osd_set_schedule(osd_handle* h, const float* sqrt_ac, const float* sqrt_1m_a
   if (!h || !sqrt_ac || !sqrt_1m_ac || !post_coef || !time_emb) { set_error("null argument"); return OSD_EINVAL; }
   const Arch& a = h->arch;
   OSD_HIP(hipSetDevice(h->cfg.device));
-  OSD_HIP(hipMemcpy(h->d_sqrt_ac, sqrt_ac, a.T * 4, hipMemcpyHostToDevice));
-  OSD_HIP(hipMemcpy(h->d_sqrt_1m, sqrt_1m_ac, a.T * 4, hipMemcpyHostToDevice));
+  OSD_HIP(hipMemcpy(h->d_sqrt_ac, sqrt_ac, (size_t)a.T * 4, hipMemcpyHostToDevice));
+  OSD_HIP(hipMemcpy(h->d_sqrt_1m, sqrt_1m_ac, (size_t)a.T * 4, hipMemcpyHostToDevice));
   {
     // fold the reference's six per-step scalars into x' = A*x + B*eps + C*z (see EpiPosterior)
     std::vector<float> abc((size_t)a.T * 4, 0.f);
@@ -435,9 +451,11 @@ int osd_denoiser_forward(osd_handle* h, const float* x, const int32_t* t_index, 
   OSD_TRY(ensure_arena(&h->main, need));
   carve_fwd(a, h->main.arena, n, false, &ws);
   hipStream_t s = h->stream;
+  const int* t_idx = nullptr;
+  OSD_TRY(sanitize_t(h, s, t_index, n, &t_idx));
   OSD_TRY(run_cond(h, s, cond, n, ws));
   TrunkIn in{};
-  in.x = x; in.ldx = a.D; in.n = n; in.t_index = t_index; in.t_imm = t_all;
+  in.x = x; in.ldx = a.D; in.n = n; in.t_index = t_idx; in.t_imm = t_all;
   in.train = (flags & OSD_F_TRAIN_MODE) != 0; in.masks = masks; in.seed = seed;
   OSD_TRY(run_trunk(h, s, ws, in));
   GemmArgs g = output_proj_args(h, ws, n);
@@ -452,8 +470,11 @@ int osd_q_sample(osd_handle* h, const float* x0, const int32_t* t_index, const f
   OSD_TRY(check_rows(n));
   if (!x0 || !t_index || !x_t) { set_error("null tensor"); return OSD_EINVAL; }
   if (!noise_in && !noise_out) { set_error("noise_out is required when noise is generated"); return OSD_EINVAL; }
+  OSD_TRY(check_row_offset(row_offset, n));
   OSD_HIP(hipSetDevice(h->cfg.device));
-  OSD_HIP(launch_q_sample(h->stream, x0, t_index, h->d_sqrt_ac, h->d_sqrt_1m, noise_in, n, h->arch.D, seed, (uint32_t)row_offset, x_t, noise_out));
+  const int* t_idx = nullptr;
+  OSD_TRY(sanitize_t(h, h->stream, t_index, n, &t_idx));
+  OSD_HIP(launch_q_sample(h->stream, x0, t_idx, h->d_sqrt_ac, h->d_sqrt_1m, noise_in, n, h->arch.D, seed, (uint32_t)row_offset, x_t, noise_out));
   return OSD_OK;
 }
 
@@ -464,6 +485,7 @@ int osd_p_sample_step(osd_handle* h, const float* x_t, int32_t t, const float* c
   if (!x_t || !cond || !x_out) { set_error("null tensor"); return OSD_EINVAL; }
   const Arch& a = h->arch;
   if (t < 0 || t >= a.T) { set_error("t=%d outside [0,%d)", t, a.T); return OSD_EINVAL; }
+  OSD_TRY(check_row_offset(row_offset, n));
   if (n == 0) return OSD_OK;
   OSD_HIP(hipSetDevice(h->cfg.device));
   FwdWs ws;
@@ -558,6 +580,7 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
   OSD_TRY(check_ready(h));
   OSD_TRY(check_rows(n));
   if (!cond || !x_out) { set_error("null tensor"); return OSD_EINVAL; }
+  OSD_TRY(check_row_offset(row_offset, n));
   if (n == 0) return OSD_OK;
   OSD_HIP(hipSetDevice(h->cfg.device));
   // equal chunks (rounded up to whole 128-row tiles) of at most chunk_rows rows

@@ -29,9 +29,9 @@ __device__ __forceinline__ float swap_halves(float v) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// Hook called by every epilogue after each unit of work (an accumulator quad, a group statistic).  The
-// wave-specialised kernel (gemm_ws.h) passes a TickSync that turns some of the calls into workgroup barriers so that
-// an epilogue wave keeps rendezvousing with the MFMA waves' K loop; everywhere else it is this no-op.
+// Hook called by every epilogue after each unit of work (an accumulator quad, a group statistic): a kernel whose
+// epilogue waves must keep rendezvousing with other waves passes a Sync that turns some calls into barriers; the
+// product kernels pass this no-op.
 struct NoSync {
   __device__ __forceinline__ void tick() {}
 };
@@ -40,7 +40,6 @@ struct NoSync {
 template <bool SILU, bool ACCUM>
 struct EpiBias {
   static constexpr bool COUNTED_STORES = true;    // one float4 store per accumulator quad on a full tile
-  static constexpr int WS_SLICES = 8;             // gemm_ws.h: barriers placed inside the epilogue
   struct Args { const float* bias; float* out; int ldo; long long slice_stride; };
   static bool fast_ok(const Args& a, int F) { return F % 4 == 0 && al16(a.bias) && al16(a.out) && a.ldo % 4 == 0 && a.slice_stride % 4 == 0; }
   static __device__ __forceinline__ void slice(Args& a, int y) { a.out += (long long)y * a.slice_stride; }
@@ -78,7 +77,6 @@ struct EpiBias {
 // ---- input_proj: h = ((x W^T + b) + t_emb[t]) + c_proj   (models/diffusion.py:229-232) ----
 struct EpiInput {
   static constexpr bool COUNTED_STORES = true;
-  static constexpr int WS_SLICES = 3;             // t_emb / c_proj quads are loaded inside the slices: few, long slices
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias;
@@ -143,7 +141,6 @@ struct EpiInput {
 template <int GW, bool DROP>
 struct EpiGnSilu {
   static constexpr bool COUNTED_STORES = true;
-  static constexpr int WS_SLICES = 8;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias; const float* gamma; const float* beta;
@@ -266,7 +263,6 @@ struct EpiGnSilu {
 // differs from the reference's op order by a few ulp of the same intermediate magnitudes.
 struct EpiPosterior {
   static constexpr bool COUNTED_STORES = true;
-  static constexpr int WS_SLICES = 8;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias;
@@ -302,8 +298,7 @@ struct EpiPosterior {
     const float* c = a.coef + 4 * t;
     const float cA = c[0], cB = c[1], cC = c[2];
     const float* zbase = a.z ? a.z + (long long)(a.t_first - t) * a.z_step_stride : nullptr;
-    // every x_t quad of the wave's tile is requested before the first one is used (one latency, not sixteen; the
-    // wave-specialised kernel places barriers between quads, which the compiler will not move loads across)
+    // every x_t quad of the wave's tile is requested before the first one is used (one latency, not sixteen)
     float4 xq[NFB][NPB][4];
     OSD_FOR_QUADS(fb, pb, q) {
       const int p = pw + 32 * pb + l31;
@@ -343,7 +338,6 @@ struct EpiPosterior {
 // d = (acc + bias) - noise;  loss += sum d^2 * inv_count;  dout = d * gscale
 struct EpiMse {
   static constexpr bool COUNTED_STORES = false;   // dout / pred are optional
-  static constexpr int WS_SLICES = 4;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias; const float* noise; int ldn;
@@ -400,7 +394,6 @@ struct EpiMse {
 // acc = x_f . y_p;  d2 = |x_f|^2 + |y_p|^2 - 2 acc;  sum += exp(-gamma * max(d2, 0)) over the valid tile
 struct EpiRbfSum {
   static constexpr bool COUNTED_STORES = false;   // stores nothing
-  static constexpr int WS_SLICES = 4;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args { const float* sqa; const float* sqb; float gamma; double* sum; };
   static bool fast_ok(const Args& a, int F) { return F % 4 == 0 && al16(a.sqa); }

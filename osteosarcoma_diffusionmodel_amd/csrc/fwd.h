@@ -23,5 +23,7 @@ int refresh_derived(osd_handle* h, hipStream_t s);
 GemmArgs output_proj_args(osd_handle* h, const FwdWs& ws, int64_t n);
 int check_ready(osd_handle* h);
 int check_rows(int64_t n);
+int check_row_offset(int64_t row_offset, int64_t n);
+int sanitize_t(osd_handle* h, hipStream_t s, const int32_t* t_index, int64_t n, const int** out);
 
 }  // namespace osd

@@ -101,6 +101,8 @@ struct osd_handle {
   float* train_arena = nullptr;
   int64_t train_arena_floats = 0;
   float* loss_dev = nullptr;
+  int* t_san = nullptr;              // clamped copy of a caller-supplied t_index (sanitize_t)
+  int64_t t_san_cap = 0;
   double* normsq_dev = nullptr;
   // weight-gradient side stream of the backward pass and its fork/join events
   hipStream_t wgrad_stream = nullptr;

@@ -80,6 +80,20 @@ hipError_t launch_q_sample(hipStream_t s, const float* x0, const int* t, const f
   return hipGetLastError();
 }
 
+// caller-supplied timestep indices clamped into [lo, hi]: an index outside [0, T) is a caller error (the Python
+// shim raises IndexError as the reference's buffer gather would); the clamp only keeps the table gathers in bounds
+__global__ void k_clamp_int(const int* in, int64_t n, int lo, int hi, int* out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int v = in[i];
+    out[i] = v < lo ? lo : (v > hi ? hi : v);
+  }
+}
+hipError_t launch_clamp_int(hipStream_t s, const int* in, int64_t n, int lo, int hi, int* out) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_clamp_int, ew_grid(n), 256, 0, s, in, n, lo, hi, out);
+  return hipGetLastError();
+}
+
 // torch.randint(0, T, (B,)) stand-in (models/diffusion.py:361): uniform ints from Philox.
 __global__ void k_randint(int* out, int64_t n, int hi, uint64_t seed, uint32_t row_offset) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

@@ -3,7 +3,6 @@
 #include <vector>
 #include "gemm.h"
 #include "gemm_glds.h"
-#include "gemm_ws.h"
 #include <type_traits>
 
 namespace osd {
@@ -31,7 +30,7 @@ inline bool use_tile64(int F, int P) {
 
 // Every instantiation registers itself at load time; prepare_kernels() (called from
 // osd_create, never inside a stream capture) raises each kernel's dynamic-LDS limit.
-struct KernelReg { const void* fn; int lds_bytes; bool optional = false; };
+struct KernelReg { const void* fn; int lds_bytes; };
 std::vector<KernelReg>& kernel_registry();
 hipError_t prepare_kernels();
 
@@ -103,38 +102,12 @@ hipError_t launch_gemm_glds(hipStream_t s, const GemmArgs& g0, const typename Ep
   return hipGetLastError();
 }
 
-template <class Epi>
-struct WsRegistrar {
-  WsRegistrar() { kernel_registry().push_back({reinterpret_cast<const void*>(gemm_ws_kernel<Epi>), WsCfg::LDS_BYTES, true}); }
-  static WsRegistrar instance;
-};
-template <class Epi>
-WsRegistrar<Epi> WsRegistrar<Epi>::instance;
-
-bool ws_available(); // false when the device refused the kernel's LDS size
-int ws_mode();        // OSD_WS env / osd_set_option("wave_specialized"): 1 = wave-specialised persistent kernel (gemm_ws.h) for the 128x128 forward tiles
-
-template <class Epi>
-hipError_t launch_gemm_ws(hipStream_t s, const GemmArgs& g, const typename Epi::Args& ea) {
-  (void)&WsRegistrar<Epi>::instance;
-  const int nft = (g.F + WsCfg::BF - 1) / WsCfg::BF, npt = (g.P + WsCfg::BP - 1) / WsCfg::BP;
-  const int nvb = 8 * nft * ((npt + 7) / 8);
-  const int grid = nvb < 256 ? nvb : 256;              // one 12-wave workgroup per CU (128 KB of LDS each)
-  hipLaunchKernelGGL((gemm_ws_kernel<Epi>), dim3(grid), dim3(WsCfg::THREADS), WsCfg::LDS_BYTES, s, g, ea);
-  return hipGetLastError();
-}
-
 // a_zero_padded only matters for the forward (KC x KC) layout.
 template <class T, bool AKC, bool BKC, class Epi>
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, const typename Epi::Args& ea, bool a_zero_padded = false) {
   if (g.F <= 0 || g.P <= 0) return hipSuccess;
   if constexpr (AKC && BKC) {
     if (glds_ok(g, a_zero_padded) && Epi::fast_ok(ea, g.F)) {
-      if constexpr (std::is_same<T, TileBig>::value && Epi::COUNTED_STORES) {
-        const long tiles = (long)((g.F + T::BF - 1) / T::BF) * ((g.P + T::BP - 1) / T::BP);
-        const int wm = ws_mode();
-        if (wm && ws_available() && g.K >= 4 * BK && (tiles >= 512 || wm == 2 || g.stamps)) return launch_gemm_ws<Epi>(s, g, ea);
-      }
       return launch_gemm_glds<T, Epi>(s, g, ea);
     }
   }

@@ -282,6 +282,7 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   OSD_TRY(check_rows(n));
   if (!x0 || !cond || !loss_out) { set_error("null tensor"); return OSD_EINVAL; }
   if (n == 0) { set_error("empty batch"); return OSD_EINVAL; }
+  OSD_TRY(check_row_offset(row_offset, n));
   const Arch& a = h->arch;
   const ParamMap& pm = a.pm;
   const int n_buckets = a.n_blocks + 2;
@@ -319,7 +320,8 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   // ---- forward (models/diffusion.py:361-377) ----
   // the t_emb table and the padded input_proj.weight follow the current parameters
   OSD_TRY(refresh_derived(h, s));
-  const int* t_idx = t_index;
+  const int* t_idx = nullptr;
+  OSD_TRY(sanitize_t(h, s, t_index, n, &t_idx));
   if (!t_idx) { OSD_HIP(launch_randint(s, w.t_idx, n, a.T, seed, roff)); t_idx = w.t_idx; }
   OSD_HIP(launch_q_sample(s, x0, t_idx, h->d_sqrt_ac, h->d_sqrt_1m, noise, n, D, seed, roff, w.x_t, w.noise));
   const float* eps_true = noise ? noise : w.noise;
@@ -365,16 +367,19 @@ int osd_denoiser_forward_train(osd_handle* h, const float* x_t, const int32_t* t
   OSD_TRY(check_ready(h));
   OSD_TRY(check_rows(n));
   if (!x_t || !t_index || !cond || !eps_out || n == 0) { set_error("null tensor or empty batch"); return OSD_EINVAL; }
+  OSD_TRY(check_row_offset(row_offset, n));
   const Arch& a = h->arch;
   OSD_HIP(hipSetDevice(h->cfg.device));
   hipStream_t s = h->stream;
   TrainWs W;
   OSD_TRY(ensure_train_ws(h, s, n, nullptr, &W));
   h->saved_rows = -1;
+  const int* t_idx = nullptr;
+  OSD_TRY(sanitize_t(h, s, t_index, n, &t_idx));
   OSD_TRY(refresh_derived(h, s));
   OSD_TRY(cond_embed_fwd(h, s, cond, n, W));
   TrunkIn in{};
-  in.x = x_t; in.ldx = a.D; in.n = n; in.t_index = t_index; in.train = (flags & OSD_F_TRAIN_MODE) != 0; in.save = true;
+  in.x = x_t; in.ldx = a.D; in.n = n; in.t_index = t_idx; in.train = (flags & OSD_F_TRAIN_MODE) != 0; in.save = true;
   in.masks = masks; in.seed = seed; in.row_offset = (uint32_t)row_offset; in.drop_step = 0;
   OSD_TRY(run_trunk(h, s, W.f, in));
   GemmArgs g = output_proj_args(h, W.f, n);
@@ -396,14 +401,17 @@ int osd_denoiser_backward(osd_handle* h, const float* x_t, const int32_t* t_inde
   if (events && n_events != n_buckets) { set_error("expected %d events (osd_grad_buckets), got %d", n_buckets, n_events); return OSD_EINVAL; }
   for (int i = 0; i < a.pm.n_params; ++i)
     if (!grads[i]) { set_error("grads[%d] is null", i); return OSD_EINVAL; }
+  OSD_TRY(check_row_offset(row_offset, n));
   OSD_HIP(hipSetDevice(h->cfg.device));
   hipStream_t s = h->stream;
   TrainWs W;
   carve_train(a, h->train_arena, n, nullptr, &W);       // same carving as the forward call: pointers to its activations
+  const int* t_idx = nullptr;
+  OSD_TRY(sanitize_t(h, s, t_index, n, &t_idx));
   ZeroList zl{};
   add_backward_zeros(a, W, grads, &zl);
   OSD_HIP(launch_zero_many(s, zl));
-  OSD_TRY(backward_from(h, s, W, x_t, t_index, cond, n, dout, (flags & OSD_F_TRAIN_MODE) != 0, masks, seed, (uint32_t)row_offset, grads, dx_t, events));
+  OSD_TRY(backward_from(h, s, W, x_t, t_idx, cond, n, dout, (flags & OSD_F_TRAIN_MODE) != 0, masks, seed, (uint32_t)row_offset, grads, dx_t, events));
   if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
   return OSD_OK;
 }

@@ -332,6 +332,17 @@ class BiologyAwareDiffusionModel(nn.Module):
             raise RuntimeError(f"{name}: expected shape [N, {cols}], got {tuple(t.shape)}")
         return t
 
+    def _t32(self, t: torch.Tensor, n: int, device) -> torch.Tensor:
+        """Caller-supplied per-row timestep indices as device int32, range-checked on the host: the reference's
+        buffer gather (models/diffusion.py:337) raises IndexError for t outside [0, T).  Costs one sync, only on
+        the injected-t path (the default path draws t on the device)."""
+        t32 = t.to(device=device, dtype=torch.int32).contiguous()
+        if t32.numel() != n:
+            raise RuntimeError("t must have one entry per row")
+        if n and (int(t32.min()) < 0 or int(t32.max()) >= self.num_steps):
+            raise IndexError(f"timestep index out of range [0, {self.num_steps})")
+        return t32
+
     def _flags(self) -> int:
         return L.OSD_F_TRAIN_MODE if self.training else 0
 
@@ -340,9 +351,7 @@ class BiologyAwareDiffusionModel(nn.Module):
         eng = self._engine()
         x_0 = self._prep(x_0, self.data_dim, "x_0")
         n = x_0.shape[0]
-        t32 = t.to(device=x_0.device, dtype=torch.int32).contiguous()
-        if t32.numel() != n:
-            raise RuntimeError("t must have one entry per row")
+        t32 = self._t32(t, n, x_0.device)
         x_t = torch.empty_like(x_0)
         if noise is None:
             noise_out = torch.empty_like(x_0)
@@ -382,7 +391,7 @@ class BiologyAwareDiffusionModel(nn.Module):
         if isinstance(t, int):
             t_idx, t_all = None, t
         else:
-            t_idx, t_all = t.to(device=x_t.device, dtype=torch.int32).contiguous(), 0
+            t_idx, t_all = self._t32(t, n, x_t.device), 0
         flags = self._flags()
         masks = None
         if dropout_masks is not None:

@@ -64,14 +64,23 @@ class SyntheticPatientGenerator:
         if scenario:
             logger.info(f"Scenario: {scenario}")
         conditions = self.create_conditions(num_samples, scenario)
-        samples, mask = self.model.sample(conditions, num_samples=num_samples, seed=seed, row_offset=row_offset,
-                                          x_T=x_T, noise=noise, return_mutation_mask=True)
-        samples = samples.cpu().numpy()
         md, ed = self.mutation_dim, self.expression_dim
+        if hasattr(self.model, "vae"):
+            # BiologyConstrainedVAE (utils/train.py:233's dispatch; load_trained_model's "cvae" branch): the reference's
+            # generate() only ever calls model.sample(conditions, num_samples) and binarises on the host (:124-135)
+            if seed is not None or row_offset or x_T is not None or noise is not None:
+                raise ValueError("seed / row_offset / x_T / noise drive the diffusion sampler's Philox stream and are not "
+                                 "accepted for a cVAE model (pass z= to model.sample directly)")
+            samples = self.model.sample(conditions, num_samples=num_samples).cpu().numpy()
+            mutations = (samples[:, :md] > 0.5).astype(float)
+        else:
+            samples, mask = self.model.sample(conditions, num_samples=num_samples, seed=seed, row_offset=row_offset,
+                                              x_T=x_T, noise=noise, return_mutation_mask=True)
+            samples = samples.cpu().numpy()
+            # (mutations > 0.5).astype(float), evaluated by the last reverse step's epilogue on the device
+            mutations = mask.cpu().numpy().astype(float)
         expression = samples[:, md:md + ed]
         pathways = samples[:, md + ed:]
-        # (mutations > 0.5).astype(float), evaluated by the last reverse step's epilogue on the device
-        mutations = mask.cpu().numpy().astype(float)
         logger.info("Generation complete!")
         return {"mutations": mutations, "expression": expression, "pathways": pathways,
                 "conditions": conditions.cpu().numpy()}

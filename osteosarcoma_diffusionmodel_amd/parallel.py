@@ -43,6 +43,56 @@ def allreduce_buckets(flat_grad: torch.Tensor, slices: Sequence[Tuple[int, int]]
     main.wait_stream(comm_stream)
 
 
+class RcclGradComm:
+    """The library's own RCCL communicator (osd_comm_*, include/osdiff.h): the gradient all-reduce runs from C on
+    the communicator's stream, bucket by bucket behind the events of osd_train_loss_fwd_bwd, with no Python in the
+    loop.  The 128-byte rendezvous id is drawn by rank 0 and shipped through torch.distributed (any backend)."""
+
+    def __init__(self, device: torch.device):
+        import ctypes as C
+        from . import _lib as L
+        self._L, self._C = L, C
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        box = [None]
+        if self.rank == 0:
+            buf = (C.c_char * L.OSD_COMM_ID_BYTES)()
+            L.check(L.lib().osd_comm_unique_id(buf))
+            box[0] = bytes(buf.raw)
+        dist.broadcast_object_list(box, src=0)
+        uid = (C.c_char * L.OSD_COMM_ID_BYTES).from_buffer_copy(box[0])
+        self.handle = C.c_void_p()
+        dev = device.index if device.index is not None else torch.cuda.current_device()
+        L.check(L.lib().osd_comm_create(uid, self.rank, self.world, dev, C.byref(self.handle)))
+        self._starts = self._ends = None
+
+    def set_buckets(self, slices: Sequence[Tuple[int, int]]):
+        C = self._C
+        n = len(slices)
+        self._starts = (C.c_int64 * n)(*[s for s, _ in slices])
+        self._ends = (C.c_int64 * n)(*[e for _, e in slices])
+        self._n = n
+
+    def allreduce(self, engine_handle, flat_grad: torch.Tensor, events=None):
+        """begin + end: the handle's stream continues once every bucket is reduced."""
+        L, C = self._L, self._C
+        ev = None
+        if events is not None:
+            ev = (C.c_void_p * self._n)(*[e.cuda_event for e in events])
+        L.check(L.lib().osd_allreduce_grads_begin(engine_handle, self.handle, L.ptr(flat_grad), self._starts, self._ends, ev, self._n))
+        L.check(L.lib().osd_allreduce_grads_end(engine_handle, self.handle))
+
+    def close(self):
+        if self.handle:
+            self._L.lib().osd_comm_destroy(self.handle)
+            self.handle = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardComm:
     """The exchanges of row-sharded validation (third row): every rank holds a shard of the
     synthetic patients; metric accumulators are summed, the few columns a sort needs are gathered, and the

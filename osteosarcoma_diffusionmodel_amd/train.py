@@ -28,7 +28,7 @@ from torch.utils.data import DataLoader, Dataset
 
 from . import _lib as L
 from .diffusion import BiologyAwareDiffusionModel, _draw_seed
-from .parallel import allreduce_buckets, bucket_slices
+from .parallel import RcclGradComm, allreduce_buckets, bucket_slices
 
 logger = logging.getLogger(__name__)
 
@@ -77,7 +77,7 @@ def _loss_fwd_bwd(model: BiologyAwareDiffusionModel, x0, cond, grad_ptrs, *, t=N
     x0 = model._prep(x0, model.data_dim, "x_0")
     cond = model._prep(cond, model.condition_dim, "conditions")
     n = x0.shape[0]
-    t32 = None if t is None else t.to(device=x0.device, dtype=torch.int32).contiguous()
+    t32 = None if t is None else model._t32(t, n, x0.device)
     nz = None if noise is None else model._prep(noise, model.data_dim, "noise")
     flags = model._flags()
     masks = None
@@ -208,6 +208,31 @@ class FusedAdamW(torch.optim.Optimizer):
             st["step"] = torch.tensor(float(self._step))
         return super().state_dict()
 
+    def load_state_dict(self, state_dict):
+        """Restore from a ``torch.optim.AdamW``-layout state dict (this class's own or the reference's
+        ``optimizer_state_dict``, utils/train.py:281): the moments are copied INTO the flat buffers the fused kernel
+        reads, the per-parameter state is re-pointed at those views and the step counter follows the loaded one."""
+        super().load_state_dict(state_dict)
+        steps = set()
+        with torch.no_grad():
+            for p, o, n in zip(self.flat.params, self.flat.offsets[:-1], self.flat.numels):
+                st = self.state.get(p, {})
+                m_view = self.exp_avg[o:o + n].view_as(p)
+                v_view = self.exp_avg_sq[o:o + n].view_as(p)
+                if "exp_avg" in st:
+                    m_view.copy_(st["exp_avg"])
+                    v_view.copy_(st["exp_avg_sq"])
+                    steps.add(int(float(st["step"])))
+                else:                                   # a parameter the saved optimizer never stepped
+                    m_view.zero_()
+                    v_view.zero_()
+                self.state[p] = {"step": torch.tensor(0.0), "exp_avg": m_view, "exp_avg_sq": v_view}
+        if len(steps) > 1:
+            raise ValueError(f"FusedAdamW steps all parameters together but the loaded state has step counts {sorted(steps)}")
+        self._step = steps.pop() if steps else 0
+        for st in self.state.values():
+            st["step"] = torch.tensor(float(self._step))
+
     def zero_grad(self, set_to_none: bool = True):
         # osd_train_loss_fwd_bwd overwrites the gradients; autograd (the cVAE path) accumulates into the flat views
         if not self.overwrites_grads:
@@ -301,7 +326,10 @@ class Trainer:
     permutation of the global batch)."""
 
     def __init__(self, model: nn.Module, train_loader: DataLoader, val_loader: DataLoader, config: dict,
-                 device: str = "cuda"):
+                 device: str = "cuda", *, comm: Optional[str] = None):
+        """``comm``: how the data-parallel gradient exchange is driven -- "torch" (``torch.distributed.all_reduce``
+        per bucket on a side stream; any backend, the default) or "rccl" (the library's own RCCL communicator,
+        ``osd_allreduce_grads_begin/end``; needs one GPU per rank).  ``OSD_COMM`` in the environment sets the default."""
         self.model = model.to(device)
         self.train_loader, self.val_loader = train_loader, val_loader
         self.config, self.device = config, device
@@ -333,12 +361,40 @@ class Trainer:
         self._grad_ptrs = L.ptr_array(self.flat.grad_views)
         self._events = None
         self._comm_stream = None
+        self._rccl = None
+        import os
+        self.comm_kind = (comm or os.environ.get("OSD_COMM", "torch")).lower()
+        if self.comm_kind not in ("torch", "rccl"):
+            raise ValueError(f"comm must be 'torch' or 'rccl', got {self.comm_kind!r}")
+        if self.dist:
+            # replicas must start identical whatever RNG state each rank built its model with (rank 0 wins), and
+            # BatchNorm running statistics (cVAE) likewise; the engine then re-derives its tables
+            with torch.no_grad():
+                self._bcast(self.flat.flat)
+                for b in self.model.buffers():
+                    if b.is_floating_point() or b.dtype in (torch.int64, torch.int32):
+                        self._bcast(b)
+            for e in getattr(self.model, "_engines", {}).values():
+                e._sig = None
         if self.dist and not self.is_vae:
             self._events = [torch.cuda.Event() for _ in self.buckets]
             for e in self._events:
                 e.record()            # materialise the hipEvent_t handles
-            self._comm_stream = torch.cuda.Stream()
+            if self.comm_kind == "rccl":
+                self._rccl = RcclGradComm(self.flat.flat.device)
+                self._rccl.set_buckets(self._slices)
+            else:
+                self._comm_stream = torch.cuda.Stream()
         self.global_step = 0
+
+    def _bcast(self, t: torch.Tensor):
+        """Broadcast from rank 0 in place (staged through the host when the backend is gloo)."""
+        if torch.distributed.get_backend() == "nccl":
+            torch.distributed.broadcast(t, src=0)
+        else:
+            h = t.detach().cpu()
+            torch.distributed.broadcast(h, src=0)
+            t.copy_(h)
 
     # one optimisation step on an already device-resident (and mixed) batch
     def train_step(self, data, conditions, survival=None, *, t=None, noise=None, dropout_masks=None, seed=None, **vae_kw) -> torch.Tensor:
@@ -358,7 +414,10 @@ class Trainer:
         loss = _loss_fwd_bwd(self.model, data, conditions, self._grad_ptrs, t=t, noise=noise, dropout_masks=dropout_masks, seed=seed,
                              row_offset=self.rank * data.shape[0], loss_scale=1.0 / self.world, events=self._events)
         if self.dist:
-            allreduce_buckets(self.flat.grad, self._slices, self._events, self._comm_stream)
+            if self._rccl is not None:
+                self._rccl.allreduce(self.model._engine().handle, self.flat.grad, self._events)
+            else:
+                allreduce_buckets(self.flat.grad, self._slices, self._events, self._comm_stream)
         self.optimizer.step()
         self.global_step += 1
         return loss

@@ -27,6 +27,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.osd_version() == 100
 
 
+def test_library_exports_nothing_undeclared():
+    """The product .so carries exactly the header's entry points: diagnostics (csrc/diag, `make DIAG=1`) and
+    experiments are not part of it."""
+    import subprocess
+    from osteosarcoma_diffusionmodel_amd import _lib as L
+    out = subprocess.run(["nm", "-D", "--defined-only", str(L.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "TW"
+                       and ln.split()[-1].startswith("osd_")})
+    assert exported == declared_symbols()
+
+
 def test_arch_queries_without_gpu():
     from osteosarcoma_diffusionmodel_amd import _lib as L
     lib = L.lib()

@@ -1,6 +1,10 @@
-"""GPU: data-parallel Trainer step with 2 ranks (both on cuda:0, gloo carrying the CUDA all-reduce, which
-exercises the same code path as RCCL: per-bucket events recorded by osd_train_loss_fwd_bwd, comm stream,
-gradients pre-scaled by 1/world).  Two ranks on half batches must reproduce one process on the full batch."""
+"""GPU: data-parallel Trainer step with 2 ranks.  Two ranks on half batches must reproduce one process on the full
+batch.  Three transports of the same bucketed exchange (per-bucket events recorded by osd_train_loss_fwd_bwd,
+gradients pre-scaled by 1/world):
+  * gloo, both ranks on cuda:0 -- runs on a 1-GPU box;
+  * nccl (= RCCL) through torch.distributed on a side stream, one device per rank;
+  * the library's own RCCL communicator (osd_allreduce_grads_begin/end), one device per rank.
+The two RCCL cases need >= 2 GPUs and are skipped otherwise (utils/train.py:204-250 under data parallel)."""
 import os
 import socket
 
@@ -29,18 +33,23 @@ def _data():
             torch.randint(0, 100, (B,), generator=g), torch.randn(B, 40, generator=g))
 
 
-def _worker(rank, world, port, save_dir, q):
+def _worker(rank, world, port, save_dir, q, backend, comm):
     import torch.distributed as dist
     from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel
     from osteosarcoma_diffusionmodel_amd.train import Trainer
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        torch.manual_seed(0)
+        torch.manual_seed(rank)            # ranks build DIFFERENT initial weights: the Trainer's broadcast must fix that
         m = BiologyAwareDiffusionModel(config=_conf(save_dir), **SM)
-        tr = Trainer(m, [], [], _conf(save_dir), device="cuda")
+        tr = Trainer(m, [], [], _conf(save_dir), device="cuda", comm=comm)
         assert tr.dist and tr.world == world and tr._events is not None
+        assert (tr._rccl is not None) == (comm == "rccl")
         m.train()
         x, c, t, nz = _data()
         half = x.shape[0] // world
@@ -54,7 +63,10 @@ def _worker(rank, world, port, save_dir, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_process(tmp_path):
+@pytest.mark.parametrize("backend,comm", [("gloo", "torch"), ("nccl", "torch"), ("nccl", "rccl")])
+def test_two_rank_step_equals_single_process(tmp_path, backend, comm):
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank")
     from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel
     from osteosarcoma_diffusionmodel_amd.train import Trainer
     s = socket.socket()
@@ -63,7 +75,7 @@ def test_two_rank_step_equals_single_process(tmp_path):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q, backend, comm)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])

@@ -1,5 +1,6 @@
-"""GPU: row-sharded validation (BASELINE config 5 / SURVEY section 8e): two ranks on cuda:0 (gloo carrying the exchanges,
-the same ShardComm code path as RCCL) each hold half of the synthetic patients; ``validate_all`` must return what one
+"""GPU: row-sharded validation (BASELINE config 5 / SURVEY section 8e): two ranks -- on cuda:0 with gloo carrying the
+exchanges (runs on a 1-GPU box), and on one device each over nccl = RCCL (skipped below 2 GPUs) -- each hold half of the
+synthetic patients; ``validate_all`` must return what one
 process returns on all rows.  Exact for the integer statistics (KS, co-occurrence), 1e-6 for the fp32 Gram sums."""
 import os
 import socket
@@ -34,13 +35,17 @@ def _frames():
     return rm, re, rp, sm, se, sp, pgm
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend):
     import torch.distributed as dist
     from osteosarcoma_diffusionmodel_amd.parallel import shard_rows
     from osteosarcoma_diffusionmodel_amd.validation import BiologicalValidator
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rm, re, rp, sm, se, sp, pgm = _frames()
         off, cnt = shard_rows(len(sm), rank, world)
@@ -57,7 +62,10 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_validate_all_equals_single_process():
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_sharded_validate_all_equals_single_process(backend):
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank")
     from osteosarcoma_diffusionmodel_amd.validation import BiologicalValidator
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -65,7 +73,7 @@ def test_sharded_validate_all_equals_single_process():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
