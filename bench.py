@@ -8,13 +8,25 @@ threshold of utils/generate.py:135) of `--patients` conditional patients per GPU
 shape (D = 50 + 1900 + 50, hidden [256,512,256], cond 3, cosine schedule, three scenario
 condition rows of config.yaml:124-141), on synthetic inputs already resident in HBM.  Rows are
 sharded over ranks with no collective ("weak" scaling: per-GPU patients fixed).  Rank 0 prints ONE
-JSON line; `roofline` is for the dominant fused GEMM kernel, `cpu_baseline` is the CPU oracle
-(PyTorch CPU ops, validated against the reference) timed on this host on a bounded sample.
+JSON line:
+  * `roofline`      the dominant kernel of the timed region, measured live with HIP events;
+  * `train`         the secondary metric (BASELINE config 2 at N = 1, config 4 = data-parallel at N > 1):
+                    utils/train.py:204-250 per step (mixup, fused forward/backward, bucketed gradient
+                    all-reduce over RCCL overlapped with backward, clip + AdamW) at 4096 rows per GPU;
+  * `cpu_baseline`  the CPU oracle (PyTorch CPU ops, validated against the reference) timed on this
+                    host: p_sample at B = 1024 and 4096, one un-extrapolated sample(N = 1024, T = 1000) and
+                    one training step (N = 1 only).
+
+Launched with WORLD_SIZE unset and --gpus N > 1 the script starts the N ranks itself (a child
+`python -m torch.distributed.run`, started BEFORE this process touches the GPU) and returns the child's
+exit code; under torchrun it is one of the ranks.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -22,11 +34,11 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBPS = 8000.0
 FLOP_PER_PATIENT_STEP = 5_193_728      # 2 x 2 596 864 MAC, GEMMs only
+TRAIN_FLOP_PER_SAMPLE = 14.56e6        # fwd 5.194 + dgrad 4.170 + wgrad 5.194 MFLOP
+TRAIN_BATCH = 4096                     # per GPU (BASELINE configs 2 and 4)
 
 CONF = {"model": {"latent_dim": 128, "hidden_dims": [256, 512, 256], "gnn": {"dropout": 0.2},
                   "diffusion": {"num_steps": 1000, "beta_schedule": "cosine"},
@@ -36,38 +48,7 @@ SCENARIOS = [dict(survival_time=2000, event_occurred=0, metastasis_at_diagnosis=
              dict(survival_time=800, event_occurred=0, metastasis_at_diagnosis=0)]
 
 
-def scenario_conditions(n, offset):
-    rows = torch.tensor([[(s["survival_time"] - 800) / 500, s["event_occurred"], s["metastasis_at_diagnosis"]]
-                         for s in SCENARIOS], dtype=torch.float32)
-    idx = (torch.arange(n) + offset) % 3
-    return rows[idx]
-
-
-def cpu_baseline(state_dict, budget_s=20.0):
-    """CPU oracle p_sample steps at B=1024 on all host cores, extrapolated to T=1000."""
-    from oracle import diffusion_oracle as O
-    sd = {k: v.detach().cpu() for k, v in state_dict.items() if k.startswith(("condition_embed", "unet"))}
-    bufs = O.schedule_buffers("cosine", 1000)
-    B = 1024
-    g = torch.Generator().manual_seed(1234)
-    x = torch.randn(B, 2000, generator=g)
-    cond = scenario_conditions(B, 0)
-    z = torch.randn(B, 2000, generator=g)
-    times = []
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        O.p_sample(sd, bufs, x, 500, cond, z, 3, 128)            # warm-up
-        while time.perf_counter() - t0 < budget_s and len(times) < 40:
-            s = time.perf_counter()
-            O.p_sample(sd, bufs, x, 500, cond, z, 3, 128)
-            times.append(time.perf_counter() - s)
-    med = float(np.median(times))
-    return {"value": B / (med * 1000), "unit": "patients/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"median of {len(times)} oracle p_sample steps at B={B}, D=2000 (x1000 steps extrapolated)",
-            "host_cpus": os.cpu_count()}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -75,31 +56,214 @@ def main():
     ap.add_argument("--patients", type=int, default=100_000, help="patients per GPU per step")
     ap.add_argument("--chunk-rows", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0)
+    ap.add_argument("--sampler", choices=["auto", "chain", "graph"], default="auto",
+                    help="reverse-chain engine: persistent chain kernel, per-layer kernels under a hipGraph, or the library default")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-full-sample", action="store_true", help="skip the un-extrapolated CPU sample(N=1024, T=1000) leg")
+    ap.add_argument("--no-train", action="store_true", help="skip the training leg")
+    ap.add_argument("--train-steps", type=int, default=40)
     ap.add_argument("--profile-rows", type=int, default=0, help="rows for the per-kernel event timing (default: chunk)")
     ap.add_argument("--profile-only", action="store_true", help="run only the per-kernel roofline leg (for rocprofv3 --stats)")
-    args = ap.parse_args()
+    ap.add_argument("--train-only", action="store_true", help="run only the training leg (for rocprofv3 --stats)")
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """--gpus N without a torchrun environment: become the launcher.  Nothing in this process has touched the GPU
+    (no HIP call, no torch.cuda.is_available()), and the ranks are CHILD processes, never an exec of this one."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def scenario_conditions(n, offset):
+    import torch
+    rows = torch.tensor([[(s["survival_time"] - 800) / 500, s["event_occurred"], s["metastasis_at_diagnosis"]]
+                         for s in SCENARIOS], dtype=torch.float32)
+    idx = (torch.arange(n) + offset) % 3
+    return rows[idx]
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU oracle legs (SURVEY section 8d "CPU baseline timing"); rank 0, N = 1 only
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(state_dict, full_sample=True, budget_s=12.0):
+    import numpy as np
+    import torch
+    from oracle import diffusion_oracle as O
+    sd = {k: v.detach().cpu() for k, v in state_dict.items() if k.startswith(("condition_embed", "unet"))}
+    bufs = O.schedule_buffers("cosine", 1000)
+    g = torch.Generator().manual_seed(1234)
+    legs = {}
+
+    def p_sample_leg(B, max_steps):
+        x = torch.randn(B, 2000, generator=g)
+        cond = scenario_conditions(B, 0)
+        z = torch.randn(B, 2000, generator=g)
+        times = []
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.p_sample(sd, bufs, x, 500, cond, z, 3, 128)            # warm-up
+            while time.perf_counter() - t0 < budget_s and len(times) < max_steps:
+                s = time.perf_counter()
+                O.p_sample(sd, bufs, x, 500, cond, z, 3, 128)
+                times.append(time.perf_counter() - s)
+        med = float(np.median(times))
+        return {"patients_per_s": B / (med * 1000), "ms_per_step": 1e3 * med, "steps_timed": len(times),
+                "how": f"median oracle p_sample step at B={B}, D=2000, x1000 steps extrapolated"}
+
+    legs["p_sample_b1024"] = p_sample_leg(1024, 40)
+    legs["p_sample_b4096"] = p_sample_leg(4096, 12)
+    # one training step: forward, autograd backward, clip_grad_norm_(1.0), AdamW -- utils/train.py:236-244
+    B = TRAIN_BATCH
+    x0 = torch.randn(B, 2000, generator=g)
+    x0[:, :50] = (x0[:, :50] > 0).float()
+    cond = torch.randn(B, 3, generator=g)
+    masks = [(torch.rand(B, w, generator=g) >= 0.2).float() for w in (512, 256, 256, 512, 256)]
+    names = list(sd)
+    params = [sd[k].clone() for k in names]
+    m1 = [torch.zeros_like(p) for p in params]
+    m2 = [torch.zeros_like(p) for p in params]
+    times = []
+    for step in range(1, 4):
+        t = torch.randint(0, 1000, (B,), generator=g)
+        nz = torch.randn(B, 2000, generator=g)
+        s = time.perf_counter()
+        _, grads = O.training_loss_and_grads(dict(zip(names, params)), bufs, x0, cond, t, nz, 3, 128, masks, 0.2)
+        gl, _ = O.clip_grad_norm([grads[k] for k in names], 1.0)
+        O.adamw_step(params, gl, m1, m2, step, lr=1e-4, weight_decay=1e-5)
+        times.append(time.perf_counter() - s)
+    tmed = float(np.median(times[1:]))
+    legs["train_step_b4096"] = {"samples_per_s": B / tmed, "ms_per_step": 1e3 * tmed, "steps_timed": len(times) - 1,
+                                "how": "oracle forward + autograd backward + clip_grad_norm_ + AdamW at B=4096, D=2000, dropout 0.2"}
+    value = legs["p_sample_b1024"]["patients_per_s"]
+    sample = "median oracle p_sample step at B=1024, D=2000 (x1000 steps extrapolated)"
+    # un-extrapolated: a whole sample(N = 1024, T = 1000) -- models/diffusion.py:427-449
+    est = legs["p_sample_b1024"]["ms_per_step"]          # s for 1000 steps
+    if full_sample and est <= 200.0:
+        N = 1024
+        cond = scenario_conditions(N, 0)
+        x_T = torch.randn(N, 2000, generator=g)
+        zg = torch.Generator().manual_seed(99)
+        s = time.perf_counter()
+        with torch.no_grad():
+            out = O.sample(sd, bufs, cond, x_T, lambda t: torch.randn(N, 2000, generator=zg), 3, 128)
+        dt = time.perf_counter() - s
+        assert torch.isfinite(out).all().item()
+        legs["full_sample_n1024"] = {"patients_per_s": N / dt, "seconds": dt, "how": "one complete oracle sample(N=1024, T=1000), not extrapolated"}
+        value = N / dt
+        sample = "one complete oracle sample(N=1024, T=1000, D=2000) incl. the normal draws, not extrapolated"
+    elif full_sample:
+        legs["full_sample_n1024"] = {"skipped": f"projected {est:.0f} s exceeds the 200 s budget of this leg"}
+    return {"value": value, "unit": "patients/s", "cores": torch.get_num_threads(), "kind": "port", "sample": sample,
+            "host_cpus": os.cpu_count(), "legs": legs}
+
+
+# ------------------------------------------------------------------------------------------------
+# training leg (BASELINE config 2 / 4)
+# ------------------------------------------------------------------------------------------------
+def train_leg(dev, dist, world, rank, steps, backend):
+    """utils/train.py:204-250 per step on a device-resident synthetic dataset of 65 536 rows per rank (SURVEY section
+    8d, config 2): mixup (host draws as the reference), osd_train_loss_fwd_bwd, bucketed all-reduce, fused clip+AdamW.
+    Returns (per-rank dict).  `exposed_comm_ms` = time the handle's stream waits for the gradient exchange after its own
+    backward has finished (event pair around the wait), averaged per step."""
+    import torch
+    from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel
+    from osteosarcoma_diffusionmodel_amd.train import Trainer
+    B = TRAIN_BATCH
+    conf = {"model": dict(CONF["model"])}
+    conf["training"] = {"learning_rate": 1e-4, "weight_decay": 1e-5, "patience": 100, "min_delta": 1e-4,
+                        "augmentation": {"mixup_alpha": 0.2}, "save_dir": "/tmp/osd_bench_ckpt", "num_epochs": 1,
+                        "save_frequency": 10, "val_split": 0.2, "random_seed": 42, "batch_size": B}
+    torch.manual_seed(0)
+    model = BiologyAwareDiffusionModel(50, 1900, 50, 3, conf)
+    tr = Trainer(model, [], [], conf, device=dev)
+    model.train()
+    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    rows = 65536
+    data = torch.randn(rows, 2000, device=dev, generator=g)
+    data[:, :50] = (torch.rand(rows, 50, device=dev, generator=g) < 0.5).float()
+    cond = torch.randn(rows, 3, device=dev, generator=g)
+    surv = torch.rand(rows, device=dev, generator=g)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+
+    def one(i, timed):
+        o = (i * B) % (rows - B)
+        sl = slice(o, o + B)
+        mixed = tr.mixup({"data": data[sl], "conditions": cond[sl], "survival": surv[sl]})
+        return tr.train_step(mixed["data"], mixed["conditions"], comm_events=ev[i] if timed else None)
+
+    for i in range(5):
+        one(i, False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = one(i, True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    exposed = 0.0
+    if world > 1:
+        exposed = sum(a.elapsed_time(b) for a, b in ev) / steps
+    per_step = dt / steps
+    tf = TRAIN_FLOP_PER_SAMPLE * B * world / per_step / 1e12
+    return {"config": ("DDP diffusion training, %d x MI355X, global batch %d" % (world, B * world)) if world > 1 else
+                      "diffusion training, D=2000, T=1000, batch 4096, 1 x MI355X",
+            "ms_per_step": round(1e3 * per_step, 4), "samples_per_s": round(B * world / per_step, 1), "steps": steps,
+            "global_batch": B * world, "per_gpu_batch": B, "achieved_tflops": round(tf, 2),
+            "frac_of_fp32_mfma_peak": round(tf / world / FP32_MFMA_PEAK_TFLOPS, 4),
+            "exposed_comm_ms_per_step": round(exposed, 4), "grad_message_bytes": int(tr.flat.grad.numel()) * 4,
+            "comm": None if world == 1 else f"{tr.comm_kind} ({backend})", "final_loss": round(float(loss.item()), 5),
+            "includes": "mixup + q_sample + forward + backward + bucketed all-reduce + clip_grad_norm_ + AdamW, dropout 0.2 (Philox)"}
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+
+    import numpy as np
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # rehearsal knobs (single-GPU box): OSD_BENCH_BACKEND=gloo, OSD_BENCH_ONE_DEVICE=1 put every rank on cuda:0
-    backend = os.environ.get("OSD_BENCH_BACKEND", "nccl")
-    if os.environ.get("OSD_BENCH_ONE_DEVICE") == "1":
+    # rehearsal knob (single-GPU box): OSD_BENCH_ONE_DEVICE=1 puts every rank on cuda:0; RCCL refuses two ranks on one
+    # device, so the exchange then runs over gloo (reported in comm_backend)
+    one_device = os.environ.get("OSD_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("OSD_BENCH_BACKEND", "gloo" if one_device else "nccl")
+    if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel, _lib as L
     torch.manual_seed(0)                      # default nn.Linear / GroupNorm init, as BASELINE.md section 3
@@ -109,6 +273,8 @@ def main():
     if args.streams:
         model.sample_streams = args.streams
     model.use_graph = not args.no_graph
+    if args.sampler != "auto":
+        model.sampler = args.sampler
 
     n = args.patients
     offset = rank * n                          # global row ids: results independent of the GPU count
@@ -118,18 +284,27 @@ def main():
         out, mask = model.sample(cond, n, seed=1234 + i, row_offset=offset, return_mutation_mask=True)
         return out, mask
 
-    if args.profile_only:
-        args.steps, args.warmup, n = 0, 0, min(n, 1024)
-        cond = cond[:n].contiguous()
-    for i in range(args.warmup):
-        step(i)
-
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    line = {}
+    if args.train_only:
+        tr = train_leg(dev, dist, world, rank, args.train_steps, backend)
+        if rank == 0:
+            print(json.dumps({"train": tr}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    if args.profile_only:
+        args.steps, args.warmup, n = 0, 0, min(n, 1024)
+        cond = cond[:n].contiguous()
+    for i in range(args.warmup):
+        step(i)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -142,52 +317,19 @@ def main():
         elapsed = float(t.item())
     if args.steps:
         assert torch.isfinite(out).all().item()
+        del out, mask
     total_patients = n * world * args.steps
     value = total_patients / elapsed
+    engine_used = model.last_sampler if hasattr(model, "last_sampler") else "graph"
 
     roof, cpu = None, None
     if rank == 0:
-        # per-kernel durations with HIP events on the launch stream, same process, same shapes
-        eng = model._engine()
-        # rows per launch of the timed region: equal chunks of at most chunk_rows, whole 128-row tiles
-        chunk_cap = model.sample_chunk_rows or 65536
-        n_chunks = -(-args.patients // chunk_cap)
-        chunk_rows = min(args.patients, (-(-args.patients // n_chunks) + 127) // 128 * 128)
-        rows = args.profile_rows or chunk_rows
-        if rows > cond.shape[0]:
-            cond = scenario_conditions(rows, offset).to(dev)
-        ms = (C.c_float * 64)()
-        fl = (C.c_double * 64)()
-        ne = C.c_int()
-        pc = cond[:rows].contiguous()
-        L.check(L.lib().osd_profile_step(eng.handle, L.ptr(pc), rows, 20, ms, fl, 64, C.byref(ne)))
-        ne = ne.value
-        names = ["input_proj"] + [f"block{i // 2}.{'first' if i % 2 == 0 else 'second'}" for i in range(ne - 2)] + ["output_proj+posterior"]
-        launches = [{"launch": names[i], "ms": round(ms[i], 4), "tflops": round(fl[i] / (ms[i] * 1e-3) / 1e12, 2)} for i in range(ne)]
-        # dominant kernel class = Linear+GroupNorm(groups of 64)+SiLU (the four 512-wide launches)
-        wide = [i for i in range(1, ne - 1) if CONF["model"]["hidden_dims"][1] == 512 and launches[i]["launch"] in
-                ("block0.first", "block0.second", "block3.first", "block3.second")]
-        dom_ms = float(np.mean([ms[i] for i in wide]))
-        dom_fl = float(np.mean([fl[i] for i in wide]))
-        achieved = dom_fl / (dom_ms * 1e-3) / 1e12
-        step_ms = float(sum(ms[i] for i in range(ne)))
-        # HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes (profiles/r01_pmc.md:
-        # 2 x FETCH_SIZE + WRITE_SIZE at 32 768 rows), scaled to this launch's rows
-        traffic = None
-        tj = ROOT / "profiles" / "r01_traffic.json"
-        if tj.exists():
-            t = json.loads(tj.read_text())
-            traffic = round(t["traffic_bytes_per_launch"]["GnSilu<64> glds"] * rows / t["rows_per_launch"])
-        roof = {"bound": "mfma", "kernel": "gemm_glds_kernel<Tile<128,128,64,64>, EpiGnSilu<64>> (Linear+GroupNorm+SiLU, 512-wide layers)",
-                "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_gbps": None if traffic is None else round(traffic / (dom_ms * 1e-3) / 1e9, 1),
-                "avg_launch_ms": round(dom_ms, 4), "rows_per_launch": rows,
-                "whole_step": {"ms": round(step_ms, 3),
-                               "tflops": round(rows * FLOP_PER_PATIENT_STEP / (step_ms * 1e-3) / 1e12, 2)},
-                "launches": launches}
-        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (one host, one CPU timing)
-            cpu = cpu_baseline(model.state_dict())
+        roof = roofline_leg(model, args, cond, offset, dev, engine_used)
+    train = None
+    if not args.no_train and not args.profile_only:
+        train = train_leg(dev, dist, world, rank, args.train_steps, backend)
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and not args.profile_only:
+        cpu = cpu_baseline(model.state_dict(), full_sample=not args.no_cpu_full_sample)   # N = 1 only (one host, one CPU timing)
 
     if rank == 0:
         line = {
@@ -195,18 +337,69 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / max(args.steps, 1), 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "reverse sampling of conditional patients, T=1000, D=2000 (50 mut + 1900 expr + 50 pathway), "
-                                   "hidden [256,512,256], 3 scenario conditions, hipGraph-captured p_sample step",
+                                   "hidden [256,512,256], 3 scenario conditions (BASELINE config 3)",
                        "patients_per_gpu": n, "global_patients_per_step": n * world, "T": 1000,
                        "parallelism": f"patients sharded over {world} GPU(s), no collective",
-                       "chunk_rows": model.sample_chunk_rows or 65536, "streams": model.sample_streams or 2,
+                       "sampler": engine_used, "chunk_rows": model.sample_chunk_rows or 65536, "streams": model.sample_streams or 2,
                        "graph": model.use_graph},
+            "rccl_ranks": rccl_ranks, "comm_backend": None if world == 1 else backend,
             "achieved_tflops_end_to_end": round(value * 1000 * FLOP_PER_PATIENT_STEP / 1e12 / world, 2),
-            "roofline": roof, "cpu_baseline": cpu,
+            "frac_of_fp32_mfma_peak_end_to_end": round(value * 1000 * FLOP_PER_PATIENT_STEP / 1e12 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+            "roofline": roof, "train": train, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline_leg(model, args, cond, offset, dev, engine_used):
+    """Per-kernel durations with HIP events on the launch stream, same process, same shapes as the timed region."""
+    import numpy as np
+    import torch
+    from osteosarcoma_diffusionmodel_amd import _lib as L
+    eng = model._engine()
+    # rows per launch of the per-layer path: equal chunks of at most chunk_rows, whole 128-row tiles
+    chunk_cap = model.sample_chunk_rows or 65536
+    n_chunks = -(-args.patients // chunk_cap)
+    chunk_rows = min(args.patients, (-(-args.patients // n_chunks) + 127) // 128 * 128)
+    rows = args.profile_rows or chunk_rows
+    if rows > cond.shape[0]:
+        cond = scenario_conditions(rows, offset).to(dev)
+    ms = (C.c_float * 64)()
+    fl = (C.c_double * 64)()
+    ne = C.c_int()
+    pc = cond[:rows].contiguous()
+    L.check(L.lib().osd_profile_step(eng.handle, L.ptr(pc), rows, 20, ms, fl, 64, C.byref(ne)))
+    ne = ne.value
+    names = ["input_proj"] + [f"block{i // 2}.{'first' if i % 2 == 0 else 'second'}" for i in range(ne - 2)] + ["output_proj+posterior"]
+    launches = [{"launch": names[i], "ms": round(ms[i], 4), "tflops": round(fl[i] / (ms[i] * 1e-3) / 1e12, 2),
+                 "frac": round(fl[i] / (ms[i] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3)} for i in range(ne)]
+    wide = [i for i in range(1, ne - 1) if launches[i]["launch"] in ("block0.first", "block0.second", "block3.first", "block3.second")]
+    dom_ms = float(np.mean([ms[i] for i in wide]))
+    dom_fl = float(np.mean([fl[i] for i in wide]))
+    achieved = dom_fl / (dom_ms * 1e-3) / 1e12
+    step_ms = float(sum(ms[i] for i in range(ne)))
+    traffic, traffic_source = None, None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        tj = ROOT / "profiles" / name
+        if tj.exists():
+            t = json.loads(tj.read_text())
+            key = "GnSilu<64> glds"
+            if key in t.get("traffic_bytes_per_launch", {}):
+                traffic = round(t["traffic_bytes_per_launch"][key] * rows / t["rows_per_launch"])
+                traffic_source = f"profiles/{name} (rocprofv3 --pmc passes of an earlier run of this kernel, 2 x FETCH_SIZE + WRITE_SIZE " \
+                                 f"at {t['rows_per_launch']} rows, scaled by rows; NOT measured in this run)"
+                break
+    layer = {"bound": "mfma", "kernel": "gemm_glds_kernel<Tile<128,128,64,64>, EpiGnSilu<64>> (Linear+GroupNorm+SiLU, 512-wide layers)",
+             "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+             "traffic_gbps": None if traffic is None else round(traffic / (dom_ms * 1e-3) / 1e9, 1),
+             "avg_launch_ms": round(dom_ms, 4), "rows_per_launch": rows,
+             "whole_step": {"ms": round(step_ms, 3),
+                            "tflops": round(rows * FLOP_PER_PATIENT_STEP / (step_ms * 1e-3) / 1e12, 2)},
+             "launches": launches}
+    return layer
 
 
 if __name__ == "__main__":

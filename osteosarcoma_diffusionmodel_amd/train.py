@@ -397,7 +397,11 @@ class Trainer:
             t.copy_(h)
 
     # one optimisation step on an already device-resident (and mixed) batch
-    def train_step(self, data, conditions, survival=None, *, t=None, noise=None, dropout_masks=None, seed=None, **vae_kw) -> torch.Tensor:
+    def train_step(self, data, conditions, survival=None, *, t=None, noise=None, dropout_masks=None, seed=None, comm_events=None,
+                   **vae_kw) -> torch.Tensor:
+        """``comm_events``: an optional pair of timing ``torch.cuda.Event``s recorded on the current stream when its own
+        backward has been enqueued and again once it has waited for the gradient exchange -- their distance is the
+        exposed (not overlapped) communication time of the step (bench.py)."""
         if not self.flat.is_current():
             raise RuntimeError("model parameters were re-allocated after Trainer construction (e.g. model.to()); rebuild the Trainer")
         if self.is_vae:
@@ -413,11 +417,15 @@ class Trainer:
             return loss.detach()
         loss = _loss_fwd_bwd(self.model, data, conditions, self._grad_ptrs, t=t, noise=noise, dropout_masks=dropout_masks, seed=seed,
                              row_offset=self.rank * data.shape[0], loss_scale=1.0 / self.world, events=self._events)
+        if comm_events is not None:
+            comm_events[0].record()
         if self.dist:
             if self._rccl is not None:
                 self._rccl.allreduce(self.model._engine().handle, self.flat.grad, self._events)
             else:
                 allreduce_buckets(self.flat.grad, self._slices, self._events, self._comm_stream)
+        if comm_events is not None:
+            comm_events[1].record()
         self.optimizer.step()
         self.global_step += 1
         return loss

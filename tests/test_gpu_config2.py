@@ -6,8 +6,8 @@ slice count and slab reduction in csrc/train.hip, the two-stream backward), so l
 parameters / AdamW moments after one ``Trainer.train_step`` are compared here with the one- and the two-stream
 backward, with injected keep-masks and with the in-kernel Philox masks (the oracle is fed the host restatement of
 those).  Stated fp32 tolerances: loss 1e-5 relative; each gradient tensor max|d| <= 5e-5 * max|ref|; parameters after
-the step 2e-5 * max|ref| (+ lr-sized absolute slack where AdamW's m/sqrt(v) amplifies summation-order noise of
-near-zero gradients); first moments 1e-4, second moments 2e-4 relative.  References: models/diffusion.py:344-380,
+the step 2e-5 * max|ref| plus the gradient tolerance propagated through the first AdamW update (steep where the
+clipped gradient is comparable to eps = 1e-8); first moments 1e-4, second moments 2e-4 relative.  References: models/diffusion.py:344-380,
 utils/train.py:236-244."""
 import copy
 
@@ -67,22 +67,24 @@ def _oracle(mask_mode):
         m1 = [torch.zeros_like(sd[k]) for k in names]
         v1 = [torch.zeros_like(sd[k]) for k in names]
         O.adamw_step(p1, clipped, m1, v1, 1, lr=LR, weight_decay=WD)
-        _cache[key] = dict(loss=float(loss), grads=grads, norm=float(norm), names=names, p1=dict(zip(names, p1)),
+        _cache[key] = dict(loss=float(loss), grads=grads, norm=float(norm), names=names, p1=dict(zip(names, p1)), gclip=dict(zip(names, clipped)),
                            m1=dict(zip(names, m1)), v1=dict(zip(names, v1)))
     return _cache[key]
 
 
-def _assert_params_close(got, want, name):
-    """The first AdamW step moves every element by lr * g / (|g| + eps), i.e. by +-lr unless |g| ~ eps = 1e-8: an element
-    whose gradient is zero to within the summation-order noise may land on the other side (|d| up to 2 lr).  Such
-    elements must be rare (<= 1e-5 of the tensor + 2); every other element meets 2e-5 * max|ref|."""
-    got, want = got.double().numpy(), want.double().numpy()
+def _assert_params_close(got, want, gclip, name):
+    """The first AdamW step moves an element by lr * g / (|g| + eps) (m_hat = g, sqrt(v_hat) = |g|): +-lr for all but the
+    elements whose clipped gradient is comparable to eps = 1e-8, where the update is steep in g.  The stated gradient
+    tolerance (5e-5 * max|g| per tensor) is therefore propagated through that map: an element may deviate by
+    2e-5 * max|p| + |d step / d g| * 5e-5 * max|g|, never by more than the 2 lr of a flipped sign."""
+    got, want, g = got.double().numpy(), want.double().numpy(), np.abs(gclip.double().numpy())
     d = np.abs(got - want)
     assert np.isfinite(got).all(), name
-    assert d.max() <= 2.05 * LR, f"param {name}: max|d|={d.max():.3e} exceeds two AdamW steps"
-    tol = 2e-5 * np.abs(want).max() + 1e-8
-    bad = int((d > tol).sum())
-    assert bad <= 1e-5 * d.size + 2, f"param {name}: {bad} of {d.size} elements beyond {tol:.2e}"
+    eps = 1e-8
+    sens = LR * eps / (g + eps) ** 2
+    allowed = 2e-5 * np.abs(want).max() + 1e-8 + np.minimum(sens * GRAD_RTOL * g.max(), 2.0 * LR)
+    worst = (d - allowed).max()
+    assert worst <= 0, f"param {name}: an element exceeds its propagated tolerance by {worst:.3e} (max|d|={d.max():.3e})"
 
 
 def _model(train_streams):
@@ -124,7 +126,7 @@ def test_config2_batch_grads_and_step_vs_oracle(train_streams, mask_mode, tmp_pa
     assert_close(tr.optimizer.grad_norm.item(), ref["norm"], 2e-5, what="pre-clip gradient norm")
     osd = tr.optimizer.state_dict()
     for i, (k, p) in enumerate(m2.named_parameters()):
-        _assert_params_close(p.detach().cpu(), ref["p1"][k], k)
+        _assert_params_close(p.detach().cpu(), ref["p1"][k], ref["gclip"][k], k)
         assert_close(osd["state"][i]["exp_avg"].cpu(), ref["m1"][k], 1e-4, atol=1e-12, what=f"exp_avg {k}")
         assert_close(osd["state"][i]["exp_avg_sq"].cpu(), ref["v1"][k], 2e-4, atol=1e-16, what=f"exp_avg_sq {k}")
         assert float(osd["state"][i]["step"]) == 1.0
