@@ -85,7 +85,10 @@ int osd_destroy(osd_handle *h);
 /* Bind the HIP stream (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream). */
 int osd_set_stream(osd_handle *h, void *hip_stream);
 
-/* Tunables: "chunk_rows" (rows per sampling chunk), "n_streams" (chunks in flight). */
+/* Tunables: "sampler" (0 auto, 1 persistent chain kernel wherever the architecture allows it, 2 per-layer kernels),
+ * "chunk_rows" / "n_streams" (per-layer path: rows per sampling chunk, chunks in flight), "chain_grid" (cap on the chain
+ * kernel's workgroups), "chain_steps_per_launch" (0 = the whole chain in one launch), "chain_stagger" (shader cycles
+ * between the starts of the two workgroups of a CU), "train_streams" (1 | 2: weight gradients on a side stream). */
 int osd_set_option(osd_handle *h, const char *name, int64_t value);
 
 /* Schedule + time-embedding tables, computed by the host with the reference's own
@@ -133,6 +136,13 @@ int osd_p_sample_step(osd_handle *h, const float *x_t, int32_t t, const float *c
 int osd_sample_chain(osd_handle *h, const float *cond, int64_t n, const float *x_T,
                      const float *noises, uint64_t seed, int64_t row_offset, float *x_out,
                      float *mut_mask_out, int flags);
+/* Two engines run osd_sample_chain with identical results: the per-layer kernels (12 launches per step, replayed from a
+ * hipGraph under OSD_F_GRAPH) and, for >= ~50 000 rows of an architecture with 256/512-wide blocks in eval mode, ONE
+ * persistent kernel that carries each 128-row tile through all layers and all T steps (csrc/chain.h).  Returns the
+ * engine a call with these n / flags would use (0 per-layer, 1 chain kernel); n < 0: the engine of the last call.  The
+ * chain kernel bounds every inter-workgroup wait; if a wait expires its results are invalid and the failure is reported
+ * by the call itself under OSD_F_SYNC, else by the next osd_sample_chain on the handle (OSD_EHIP). */
+int osd_sample_engine(osd_handle *h, int64_t n, int flags);
 
 /* Training forward+backward (models/diffusion.py:344-380 + loss.backward(),
  * utils/train.py:236-239): loss (dev float[1]) and gradients of all parameters.

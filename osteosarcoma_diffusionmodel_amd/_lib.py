@@ -51,6 +51,7 @@ _SIGNATURES = {
     "osd_q_sample": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_uint64, C.c_int64, _P, _P]),
     "osd_p_sample_step": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int64, C.c_uint64, C.c_int64, _P, C.c_int]),
     "osd_sample_chain": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_uint64, C.c_int64, _P, _P, C.c_int]),
+    "osd_sample_engine": (C.c_int, [_P, C.c_int64, C.c_int]),
     "osd_train_loss_fwd_bwd": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, C.POINTER(_P), C.c_uint64, C.c_int64, C.c_int,
                                          _P, C.POINTER(_P), C.c_double, C.POINTER(_P), C.c_int]),
     "osd_denoiser_forward_train": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.POINTER(_P), C.c_uint64, C.c_int64, C.c_int, _P]),

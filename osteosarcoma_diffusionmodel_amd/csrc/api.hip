@@ -106,7 +106,7 @@ int ensure_arena(Slot* s, int64_t floats) {
   if (s->arena_floats >= floats) return OSD_OK;
   if (s->arena) { hipError_t e = hipFree(s->arena); (void)e; s->arena = nullptr; s->arena_floats = 0; }
   void* p = nullptr;
-  if (hipMalloc(&p, (size_t)floats * 4) != hipSuccess) { set_error("hipMalloc of %lld bytes failed", (long long)floats * 4); return OSD_ENOMEM; }
+  if (hipMalloc(&p, (size_t)floats * 4) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc of %lld bytes failed", (long long)floats * 4); return OSD_ENOMEM; }
   s->arena = (float*)p;
   s->arena_floats = floats;
   return OSD_OK;
@@ -263,7 +263,7 @@ int sanitize_t(osd_handle* h, hipStream_t s, const int32_t* t_index, int64_t n, 
   if (h->t_san_cap < n) {
     if (h->t_san) { OSD_HIP(hipStreamSynchronize(s)); OSD_HIP(hipFree(h->t_san)); h->t_san = nullptr; h->t_san_cap = 0; }
     const int64_t cap = (n + 1023) / 1024 * 1024;
-    if (hipMalloc((void**)&h->t_san, (size_t)cap * 4) != hipSuccess) { set_error("hipMalloc of %lld bytes failed", (long long)cap * 4); return OSD_ENOMEM; }
+    if (hipMalloc((void**)&h->t_san, (size_t)cap * 4) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc of %lld bytes failed", (long long)cap * 4); return OSD_ENOMEM; }
     h->t_san_cap = cap;
   }
   OSD_HIP(launch_clamp_int(s, t_index, n, 0, h->arch.T - 1, h->t_san));
@@ -329,6 +329,7 @@ int osd_create(const osd_config* cfg, osd_handle** out) {
   const int rc = create_device_state(h);
   if (rc != OSD_OK) {                 // nothing of a half-built handle survives (osd_destroy frees what was allocated)
     osd_destroy(h);
+    (void)hipGetLastError();          // the failed call's sticky error must not surface in a later launch check
     return rc;
   }
   *out = h;
@@ -361,6 +362,7 @@ int osd_destroy(osd_handle* h) {
   for (hipEvent_t ev : h->ev_pool) e = hipEventDestroy(ev);
   if (h->wgrad_stream) e = hipStreamDestroy(h->wgrad_stream);
   cons_free_plan(&h->cons);
+  chain_free(h);
   if (h->fork_ev) e = hipEventDestroy(h->fork_ev);
   (void)e;
   delete h;
@@ -383,6 +385,26 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "n_streams")) {
     if (value < 1 || value > 8) { set_error("n_streams must be in [1,8]"); return OSD_EINVAL; }
     h->n_streams = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "sampler")) {                 // 0 auto, 1 persistent chain kernel where supported, 2 per-layer kernels
+    if (value < 0 || value > 2) { set_error("sampler must be 0 (auto), 1 (chain kernel) or 2 (per-layer kernels)"); return OSD_EINVAL; }
+    h->sampler = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "chain_grid")) {
+    if (value < 0 || value > 65536) { set_error("chain_grid must be in [0,65536]"); return OSD_EINVAL; }
+    h->chain_grid = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "chain_steps_per_launch")) {
+    if (value < 0) { set_error("chain_steps_per_launch must be >= 0"); return OSD_EINVAL; }
+    h->chain_steps_per_launch = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "chain_stagger")) {
+    if (value < 0 || value > 100000000) { set_error("chain_stagger must be in [0,1e8] cycles"); return OSD_EINVAL; }
+    h->chain_stagger = (int)value;
     return OSD_OK;
   }
   if (!strcmp(name, "train_streams")) {
@@ -583,6 +605,13 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
   OSD_TRY(check_row_offset(row_offset, n));
   if (n == 0) return OSD_OK;
   OSD_HIP(hipSetDevice(h->cfg.device));
+  OSD_TRY(chain_check_status(h));            // a previous chain-kernel run that gave up is reported here at the latest
+  h->last_engine = chain_pick_engine(h, n, flags);
+  if (h->last_engine == 1) {
+    OSD_TRY(chain_run(h, cond, n, x_T, noises, seed, row_offset, x_out, mut_mask_out));
+    if (flags & OSD_F_SYNC) OSD_TRY(chain_check_status(h));
+    return OSD_OK;
+  }
   // equal chunks (rounded up to whole 128-row tiles) of at most chunk_rows rows
   int64_t n_chunks = (n + h->chunk_rows - 1) / h->chunk_rows;
   int64_t chunk = ((n + n_chunks - 1) / n_chunks + 127) / 128 * 128;
@@ -614,6 +643,12 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
   if (rc != OSD_OK) return rc;
   if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(h->stream));
   return OSD_OK;
+}
+
+int osd_sample_engine(osd_handle* h, int64_t n, int flags) {
+  if (!h) { set_error("null handle"); return OSD_EINVAL; }
+  if (n < 0) return h->last_engine;
+  return chain_pick_engine(h, n, flags);
 }
 
 int osd_mixup(osd_handle* h, const float* data, const float* cond, const float* surv, const int64_t* perm, double lam, int64_t n,

@@ -1,0 +1,330 @@
+// chain.h -- the persistent reverse-chain kernel: all layers of the denoiser and all T steps in ONE launch.
+//
+// models/diffusion.py:427-449 runs T sequential p_sample steps over rows that never interact (GroupNorm is per
+// row).  The per-layer kernels of gemm_glds.h pay, 12 times per step, a launch boundary, a wave of workgroups that all
+// sit in their prologue (then their epilogue) at the same moment, and a partial last round.  Here the unit of work is
+// (128-row tile, one step): a workgroup carries its tile through input_proj, the ten Linear+GroupNorm+SiLU layers and
+// output_proj + posterior update with the same MFMA tile loop and the same epilogues as the per-layer kernels; the
+// activations of the tile live in a workspace PRIVATE to the workgroup's slot (written and re-read by one CU: L2 /
+// Infinity-Cache traffic, never another workgroup's business), the chain state x stays in the caller's [n][D] tensor.
+//
+// Units are dealt round-robin: workgroup w runs units w, w + G, w + 2G, ... in order, unit u = (tile u % n_tiles,
+// step u / n_tiles).  A unit needs x_t of its tile, written by the unit n_tiles earlier (another workgroup, possibly
+// another XCD): the producer publishes with an agent-scope release behind a drained workgroup barrier and a relaxed
+// agent store of progress[tile]; the consumer polls that one word relaxed from one lane, then ONE agent-scope acquire,
+// s_waitcnt, workgroup barrier, plain loads (cdna_hip_programming.md Guideline 16).  With G <= n_tiles the producer
+// is at least one full round of units ahead, so the poll normally passes at once; dependencies always point to an
+// earlier unit in the global order, hence no cycle as long as the G workgroups are resident (the host sizes G by the
+// occupancy query).  Every spin is bounded by a wall-clock budget: on expiry the workgroup raises status[0] and
+// leaves; every other workgroup sees the flag at its next unit (or in its own spin) and leaves too.
+//
+// Balance: n_tiles * T units over G = 2 per CU workgroups differ by at most one unit (2 ms of a 4 s chain), there is
+// no kernel boundary, and the two workgroups of a CU are started half a short tile apart (the second arrival on a CU
+// sleeps `stagger` cycles once) so that one's prologue / epilogue falls into the other's MFMA loop instead of both
+// idling the matrix pipe together -- the phase lock of identical co-resident workgroups is otherwise stable.
+#pragma once
+#include "gemm_glds.h"
+#include "epilogues.h"
+#include "launch.h"
+
+namespace osd {
+
+constexpr int CHAIN_MAX_LAYERS = 24;
+enum : int { CK_INPUT = 0, CK_GN32 = 1, CK_GN64 = 2, CK_POST = 3 };
+enum : unsigned { CHAIN_OK = 0, CHAIN_TIMEOUT = 1 };
+
+struct ChainLayer {
+  const float* A; int lda;        // weights [F][K], K contiguous, readable and zero for k in [K, roundup(K, 32))
+  int K, K0;                      // reduction length; first-panel width (K0 >= K: one panel)
+  int F;                          // output features
+  int in0, ld0, in1, ld1;         // input panels: float offsets into the slot workspace (in0 < 0: the chain state x)
+  int out, ldo;                   // output: float offset into the slot workspace (unused by CK_POST)
+  int kind;
+  const float* bias; const float* gamma; const float* beta;
+};
+
+struct ChainArgs {
+  ChainLayer L[CHAIN_MAX_LAYERS];
+  int n_layers;
+  float* ws; long long ws_stride;            // slot s owns ws[s * ws_stride, (s + 1) * ws_stride)
+  float* x; int D;                           // chain state [n][D], in place
+  int n, n_tiles;
+  int t_first, n_steps;                      // this launch runs t = t_first, t_first - 1, ..., t_first - n_steps + 1
+  unsigned base_done;                        // steps of the chain completed before this launch
+  const float* cproj; int ldc;               // [n][H0]  cond_proj(condition_embed(c)), loop-invariant
+  const float* temb; int ldt;                // [T][H0]  time_proj(TimeEmbedding(t / T))
+  const float* coef;                         // [T][4]   (A_t, B_t, C_t, 0)
+  const float* z; int ldzz; long long z_step_stride; int z_t_first;      // injected draws or null -> Philox
+  uint64_t seed; uint32_t row_offset;
+  float* mut_mask; int mutation_dim;
+  unsigned* progress;                        // [n_tiles] steps completed per tile (monotonic over the launches of a chain)
+  unsigned* status;                          // [0] CHAIN_OK / CHAIN_TIMEOUT
+  unsigned* cu_arrivals;                     // [2048] zeroed per launch; null = no stagger
+  int stagger;                               // shader cycles the second workgroup of a CU waits before its first unit
+  unsigned long long spin_budget;            // s_memrealtime ticks (100 MHz) a dependency wait may take
+};
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__device__ __forceinline__ unsigned ld_relaxed_agent(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_relaxed_agent(unsigned* p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One lane waits until *word >= want (or the chain failed elsewhere, or the budget ran out).  Returns false on failure.
+__device__ __forceinline__ bool chain_wait(const unsigned* word, unsigned want, unsigned* status, unsigned long long budget) {
+  if (ld_relaxed_agent(word) >= want) return true;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    __builtin_amdgcn_s_sleep(32);
+    if (ld_relaxed_agent(word) >= want) return true;
+    if (ld_relaxed_agent(status) != CHAIN_OK) return false;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > budget) { st_relaxed_agent(status, CHAIN_TIMEOUT); return false; }
+  }
+}
+
+typedef Tile<128, 128, 64, 64> ChainTile;
+constexpr int CHAIN_LDS_BYTES = GldsTile<ChainTile>::LDS_BYTES + 16;
+
+__global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
+  typedef ChainTile T;
+  typedef GldsTile<T> G;
+  static_assert(G::NA == 4 && G::NB == 4, "staging below assumes 4 + 4 pieces per wave");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As0 = smem;
+  float* As1 = smem + G::A_ELEMS;
+  float* Bs0 = smem + 2 * G::A_ELEMS;
+  float* Bs1 = smem + 2 * G::A_ELEMS + G::B_ELEMS;
+  // leader -> workgroup: 1 = go on, 0 = leave.  In the dynamic region behind the tiles: a static __shared__ would shift
+  // the dynamic base off its 16-byte alignment (ds_read_b128 replays; Guideline 17)
+  volatile int& s_flag = *reinterpret_cast<volatile int*>(smem + 2 * (G::A_ELEMS + G::B_ELEMS));
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wf = (wave / T::NWP) * T::WF;
+  const int wp = (wave % T::NWP) * T::WP;
+  const int l31 = lane & 31, h = lane >> 5;
+  const bool leader = tid == 0;
+
+  // staging geometry (tile independent): piece j of a wave moves rows 8 * (4 j + wave) .. + 7, 16 B per lane
+  int st_row[4], st_k4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    st_row[j] = (j * 4 + wave) * 8 + (lane >> 3);
+    st_k4[j] = 4 * ((lane & 7) ^ ((st_row[j] >> 1) & 7));
+  }
+  int a_rd[T::NFB], a_sw[T::NFB], b_rd[T::NPB], b_sw[T::NPB];
+#pragma unroll
+  for (int fb = 0; fb < T::NFB; ++fb) { const int R = wf + 32 * fb + l31; a_rd[fb] = R * BK; a_sw[fb] = h ^ ((R >> 1) & 7); }
+#pragma unroll
+  for (int pb = 0; pb < T::NPB; ++pb) { const int R = wp + 32 * pb + l31; b_rd[pb] = R * BK; b_sw[pb] = h ^ ((R >> 1) & 7); }
+
+  float* const ws = a.ws + (long long)blockIdx.x * a.ws_stride;
+
+  // ---- stagger: the second workgroup to arrive on a CU starts `stagger` cycles late, once ----
+  if (a.cu_arrivals && a.stagger > 0) {
+    if (leader) {
+      const unsigned hw = __builtin_amdgcn_s_getreg(0xF804);      // HW_REG_HW_ID: cu [11:8], sh [12], se [15:13]
+      const unsigned xcc = __builtin_amdgcn_s_getreg(0xF814) & 7; // HW_REG_XCC_ID
+      const unsigned key = (xcc << 8) | ((hw >> 8) & 0xFF);
+      const unsigned r = atomicAdd(a.cu_arrivals + key, 1u);
+      s_flag = (int)(r & 1u);
+    }
+    __syncthreads();
+    const int late = s_flag;
+    __syncthreads();
+    if (late) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+
+  const long long n_units = (long long)a.n_tiles * a.n_steps;
+  for (long long u = blockIdx.x; u < n_units; u += gridDim.x) {
+    const int tile = (int)(u % a.n_tiles);
+    const int si = (int)(u / a.n_tiles);
+    const int t = a.t_first - si;
+    const int p0 = tile * T::BP;
+    const int P = (a.n - p0 < T::BP) ? a.n - p0 : T::BP;      // valid rows of this tile
+
+    // ---- dependency: x_t of this tile (written by the unit n_tiles earlier, another workgroup) ----
+    if (leader) {
+      bool ok = ld_relaxed_agent(a.status) == CHAIN_OK;
+      if (ok && si > 0) {
+        ok = chain_wait(a.progress + tile, a.base_done + (unsigned)si, a.status, a.spin_budget);
+        if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE buffer_inv sc1 after the match
+      }
+      s_flag = ok ? 1 : 0;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the barrier must not release before the invalidate is done
+    }
+    __syncthreads();
+    const int go = s_flag;
+    if (!go) return;                      // uniform over the workgroup: every wave leaves
+
+    for (int l = 0; l < a.n_layers; ++l) {
+      const ChainLayer& L = a.L[l];
+      const int F = L.F, K = L.K;
+      const float* B0 = (L.in0 < 0) ? a.x + (size_t)p0 * a.D : ws + L.in0;
+      const float* B1 = ws + L.in1;
+      const int rowsB = (L.in0 < 0) ? P : T::BP;                // the workspace always holds a full tile
+      const int nk = (K + BK - 1) / BK;
+      const int nft = (F + T::BF - 1) / T::BF;
+      for (int ft = 0; ft < nft; ++ft) {
+        const int f0 = ft * T::BF;
+        // ---- staging: direct global -> LDS DMA, XOR-swizzled 16-byte chunks (gemm_glds.h) ----
+        auto stage = [&](int k0, float* As, float* Bs, int j) {
+          const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr(As) + (unsigned)wave * 1024u);
+          const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(Bs) + (unsigned)wave * 1024u);
+          if (j < 4) {
+            int rg = f0 + st_row[j];
+            rg = rg < F ? rg : F - 1;
+            glds16(L.A + (size_t)rg * L.lda + k0 + st_k4[j], __builtin_amdgcn_readfirstlane(la + (unsigned)j * 4096u));
+          } else {
+            const int jb = j - 4;
+            const bool first = k0 < L.K0;            // uniform: K0 is a multiple of BK (or >= K)
+            const float* bb = first ? B0 : B1;
+            const int ld = first ? L.ld0 : L.ld1;
+            const int kend = first ? (L.K0 < K ? L.K0 : K) : K - L.K0;
+            int k = (first ? k0 : k0 - L.K0) + st_k4[jb];
+            k = k < kend - 4 ? k : kend - 4;
+            int rg = st_row[jb];
+            rg = rg < rowsB ? rg : rowsB - 1;
+            glds16(bb + (size_t)rg * ld + k, __builtin_amdgcn_readfirstlane(lb + (unsigned)jb * 4096u));
+          }
+        };
+#pragma unroll
+        for (int j = 0; j < 8; ++j) stage(0, As0, Bs0, j);
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the asm DMAs are invisible to hipcc's counters
+        __syncthreads();
+
+        f32x16 acc[T::NFB][T::NPB];
+#pragma unroll
+        for (int i = 0; i < T::NFB; ++i)
+#pragma unroll
+          for (int j = 0; j < T::NPB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt) {
+          const float* Ac = (kt & 1) ? As1 : As0;
+          const float* Bc = (kt & 1) ? Bs1 : Bs0;
+          float* An = (kt & 1) ? As0 : As1;
+          float* Bn = (kt & 1) ? Bs0 : Bs1;
+          const bool more = kt + 1 < nk;
+          const int kn = (kt + 1) * BK;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float av[T::NFB][4], bv[T::NPB][4];
+#pragma unroll
+            for (int fb = 0; fb < T::NFB; ++fb) {
+              const float4 tq = *reinterpret_cast<const float4*>(&Ac[a_rd[fb] + 4 * (a_sw[fb] ^ (2 * i))]);
+              av[fb][0] = tq.x; av[fb][1] = tq.y; av[fb][2] = tq.z; av[fb][3] = tq.w;
+            }
+#pragma unroll
+            for (int pb = 0; pb < T::NPB; ++pb) {
+              const float4 tq = *reinterpret_cast<const float4*>(&Bc[b_rd[pb] + 4 * (b_sw[pb] ^ (2 * i))]);
+              bv[pb][0] = tq.x; bv[pb][1] = tq.y; bv[pb][2] = tq.z; bv[pb][3] = tq.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+              for (int fb = 0; fb < T::NFB; ++fb)
+#pragma unroll
+                for (int pb = 0; pb < T::NPB; ++pb)
+                  acc[fb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[fb][e], bv[pb][e], acc[fb][pb], 0, 0, 0);
+              // the DMA of the next K tile goes out in the first quarter of the step (two pieces per k-pair group): it then
+              // has three quarters of the step to land before the barrier (gemm_glds.h)
+              if (i == 0 && more) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage(kn, An, Bn, 2 * e);
+                stage(kn, An, Bn, 2 * e + 1);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
+
+        // ---- epilogue (the per-layer kernels' own, on local row coordinates of the tile) ----
+        // per-feature parameters are fetched here, not ahead of the K loop: 96 registers held across the loop would push the
+        // kernel past 256 VGPRs, and the one L2 latency falls into the co-resident workgroup's MFMA time
+        const int fw = f0 + wf;
+        float4 p_bias[T::NFB][4], p_gamma[T::NFB][4], p_beta[T::NFB][4];
+        const bool is_gn = L.kind == CK_GN32 || L.kind == CK_GN64;
+#pragma unroll
+        for (int fb = 0; fb < T::NFB; ++fb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int f = fw + 32 * fb + 8 * q + 4 * h;
+            p_bias[fb][q] = ldq<true>(L.bias, f, F);
+            if (is_gn) { p_gamma[fb][q] = ldq<true>(L.gamma, f, F); p_beta[fb][q] = ldq<true>(L.beta, f, F); }
+            else { p_gamma[fb][q] = make_float4(1.f, 1.f, 1.f, 1.f); p_beta[fb][q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+          }
+        if (L.kind == CK_GN64 || L.kind == CK_GN32) {
+          float* outp = ws + L.out;
+          if (L.kind == CK_GN64) {
+            typedef EpiGnSilu<64, false> E;
+            E::Args ea{L.bias, L.gamma, L.beta, outp, L.ldo, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, 0, 0, 0, 0, nullptr};
+            E::Pre<T::NFB> pre;
+#pragma unroll
+            for (int fb = 0; fb < T::NFB; ++fb)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { pre.bias[fb][q] = p_bias[fb][q]; pre.gamma[fb][q] = p_gamma[fb][q]; pre.beta[fb][q] = p_beta[fb][q]; }
+            E::apply<T::NFB, T::NPB, true>(acc, ea, pre, fw, wp, lane, F, T::BP);
+          } else {
+            typedef EpiGnSilu<32, false> E;
+            E::Args ea{L.bias, L.gamma, L.beta, outp, L.ldo, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, 0, 0, 0, 0, nullptr};
+            E::Pre<T::NFB> pre;
+#pragma unroll
+            for (int fb = 0; fb < T::NFB; ++fb)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { pre.bias[fb][q] = p_bias[fb][q]; pre.gamma[fb][q] = p_gamma[fb][q]; pre.beta[fb][q] = p_beta[fb][q]; }
+            E::apply<T::NFB, T::NPB, true>(acc, ea, pre, fw, wp, lane, F, T::BP);
+          }
+        } else if (L.kind == CK_INPUT) {
+          EpiInput::Args ea{L.bias, a.temb, a.ldt, nullptr, nullptr, t, a.cproj + (size_t)p0 * a.ldc, a.ldc, ws + L.out, L.ldo};
+          EpiInput::Pre<T::NFB> pre;
+#pragma unroll
+          for (int fb = 0; fb < T::NFB; ++fb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre.bias[fb][q] = p_bias[fb][q];
+          // rows beyond P hold a clamped copy of the last valid row: computed and stored to the private tile like the others (the
+          // host pads cproj to whole tiles), never published (the posterior epilogue stores rows < P only)
+          EpiInput::apply<T::NFB, T::NPB, true>(acc, ea, pre, fw, wp, lane, F, T::BP);
+        } else {
+          EpiPosterior::Args ea{};
+          ea.bias = L.bias;
+          ea.xin = a.x + (size_t)p0 * a.D; ea.ldx = a.D;
+          ea.xout = a.x + (size_t)p0 * a.D; ea.ldo = a.D;
+          ea.coef = a.coef; ea.t_dev = nullptr; ea.t_imm = t;
+          ea.z = a.z ? a.z + (size_t)p0 * a.ldzz : nullptr; ea.ldzz = a.ldzz; ea.z_step_stride = a.z_step_stride; ea.t_first = a.z_t_first;
+          ea.seed = a.seed; ea.row_offset = a.row_offset + (uint32_t)p0;
+          ea.mut_mask = a.mut_mask ? a.mut_mask + (size_t)p0 * a.mutation_dim : nullptr; ea.mutation_dim = a.mutation_dim;
+          EpiPosterior::Pre<T::NFB> pre;
+#pragma unroll
+          for (int fb = 0; fb < T::NFB; ++fb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre.bias[fb][q] = p_bias[fb][q];
+          EpiPosterior::apply<T::NFB, T::NPB, true>(acc, ea, pre, fw, wp, lane, F, P);
+        }
+        // every wave's stores have left before any wave stages the next tile's operands (which may be this output)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+
+    // ---- publish x_{t-1} of this tile: all waves drained (above), then ONE agent-scope release and the progress word ----
+    if (leader) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // hipcc may drop the fence's own wait (Guideline 16, pitfall 12)
+      st_relaxed_agent(a.progress + tile, a.base_done + (unsigned)si + 1u);
+    }
+  }
+}
+
+}  // namespace osd

@@ -1,0 +1,201 @@
+// chain.hip -- host side of the persistent reverse-chain kernel (chain.h): eligibility, workspace, launch, status.
+#include <algorithm>
+#include <vector>
+#include "chain.h"
+#include "handle.h"
+#include "kernels.h"
+#include "fwd.h"
+
+namespace osd {
+
+static int64_t up64(int64_t v) { return (v + 63) / 64 * 64; }
+
+// The chain kernel covers the 128 x 128 tile with GroupNorm groups of 32 or 64 channels (block widths 256 / 512, the
+// BASELINE shape and its neighbours) in eval mode; everything else runs on the per-layer kernels.
+bool chain_supported(const Arch& a) {
+  if (a.D % 4 || a.H0 % 4) return false;
+  for (int c : a.block_out)
+    if (c != 256 && c != 512) return false;
+  if (a.H0 != 256 && a.H0 != 512) return false;
+  if ((int)a.layers.size() + 2 > CHAIN_MAX_LAYERS) return false;
+  for (const LayerDesc& l : a.layers)
+    if (l.K1 % BK || (l.K1 + l.K2) % BK) return false;        // panel switch on a K-step boundary, no K tail (block weights are not padded)
+  return true;
+}
+
+struct ChainDev { int occ = 0; int cus = 0; bool ready = false; };
+static ChainDev g_chain_dev[16];
+
+static int chain_device_limits(int device, int* max_grid) {
+  if (device < 0 || device >= 16) { set_error("device %d out of range", device); return OSD_EINVAL; }
+  ChainDev& d = g_chain_dev[device];
+  if (!d.ready) {
+    OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
+    int occ = 0;
+    OSD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, chain_kernel, NTHREADS, CHAIN_LDS_BYTES));
+    hipDeviceProp_t prop;
+    OSD_HIP(hipGetDeviceProperties(&prop, device));
+    d.occ = occ < 2 ? occ : 2;              // two 64 KB tiles per CU by design
+    d.cus = prop.multiProcessorCount;
+    d.ready = true;
+  }
+  *max_grid = d.occ * d.cus;
+  return OSD_OK;
+}
+
+// 0 = per-layer kernels (eager or hipGraph), 1 = persistent chain kernel
+int chain_pick_engine(osd_handle* h, int64_t n, int flags) {
+  if (h->sampler == 2) return 0;
+  if ((flags & OSD_F_TRAIN_MODE) && h->cfg.dropout_p > 0.f) return 0;       // dropout inside the chain: per-layer kernels
+  if (!chain_supported(h->arch)) return 0;
+  if (h->sampler == 1) return 1;
+  int max_grid = 0;
+  if (chain_device_limits(h->cfg.device, &max_grid) != OSD_OK || max_grid < 2) return 0;
+  const int64_t n_tiles = (n + ChainTile::BP - 1) / ChainTile::BP;
+  return n_tiles * 4 >= (int64_t)max_grid * 3 ? 1 : 0;                        // at least 3/4 of the slots get a tile
+}
+
+static int ensure_buf(float** p, int64_t* cap, int64_t floats, hipStream_t s) {
+  if (*cap >= floats) return OSD_OK;
+  if (*p) { OSD_HIP(hipStreamSynchronize(s)); OSD_HIP(hipFree(*p)); *p = nullptr; *cap = 0; }
+  void* q = nullptr;
+  if (hipMalloc(&q, (size_t)floats * 4) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc of %lld bytes failed", (long long)floats * 4); return OSD_ENOMEM; }
+  *p = (float*)q;
+  *cap = floats;
+  return OSD_OK;
+}
+
+// Blocks until the previous chain's status word is known; OSD_EHIP if that chain gave up in a dependency wait.
+int chain_check_status(osd_handle* h) {
+  if (!h->chain_pending || !h->chain_sync) return OSD_OK;
+  unsigned st = 0;
+  OSD_HIP(hipMemcpyAsync(&st, h->chain_sync, 4, hipMemcpyDeviceToHost, h->stream));
+  OSD_HIP(hipStreamSynchronize(h->stream));
+  h->chain_pending = false;
+  if (st != CHAIN_OK) {
+    set_error("the reverse-chain kernel gave up waiting for a row tile of an earlier step (status %u): its results are invalid; "
+              "the workgroups were probably not all resident -- retry with osd_set_option(\"sampler\", 2)", st);
+    return OSD_EHIP;
+  }
+  return OSD_OK;
+}
+
+int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, const float* noises, uint64_t seed, int64_t row_offset,
+              float* x_out, float* mut_mask_out) {
+  const Arch& a = h->arch;
+  const int D = a.D, T = a.T, H0 = a.H0;
+  hipStream_t s = h->stream;
+  OSD_TRY(chain_check_status(h));
+  int max_grid = 0;
+  OSD_TRY(chain_device_limits(h->cfg.device, &max_grid));
+  if (max_grid < 1) { set_error("the chain kernel does not fit this device"); return OSD_EUNSUPPORTED; }
+  const int BP = ChainTile::BP;
+  const int n_tiles = (int)((n + BP - 1) / BP);
+  int grid = std::min(n_tiles, max_grid);
+  if (h->chain_grid > 0) grid = std::min(grid, h->chain_grid);
+
+  // ---- per-slot activation workspace: h0, then (mid, out) of every block ----
+  ChainArgs ca{};
+  int64_t off = 0;
+  auto take = [&](int64_t floats) { const int64_t o = off; off += up64(floats); return (int)o; };
+  const int o_h0 = take((int64_t)BP * H0);
+  std::vector<int> o_mid(a.n_blocks), o_out(a.n_blocks);
+  for (int b = 0; b < a.n_blocks; ++b) { o_mid[b] = take((int64_t)BP * a.block_out[b]); o_out[b] = take((int64_t)BP * a.block_out[b]); }
+  ca.ws_stride = off;
+  OSD_TRY(ensure_buf(&h->chain_ws, &h->chain_ws_floats, (int64_t)max_grid * off, s));
+  ca.ws = h->chain_ws;
+
+  // ---- conditioning for all rows, hoisted out of the chain (loop-invariant in eval mode): ce1, ce2, cproj padded to whole tiles ----
+  const int64_t rows_pad = (int64_t)n_tiles * BP;
+  const int64_t c_off_ce2 = up64(n * 64), c_off_cp = c_off_ce2 + up64(n * 64);
+  OSD_TRY(ensure_buf(&h->chain_cond, &h->chain_cond_floats, c_off_cp + up64(rows_pad * H0), s));
+  FwdWs cw;
+  cw.ce1 = h->chain_cond; cw.ce2 = h->chain_cond + c_off_ce2; cw.cproj = h->chain_cond + c_off_cp;
+  OSD_TRY(run_cond(h, s, cond, n, cw));
+  if (rows_pad > n) OSD_HIP(hipMemsetAsync(cw.cproj + n * H0, 0, (size_t)(rows_pad - n) * H0 * 4, s));
+
+  // ---- x_T ----
+  if (x_T) OSD_HIP(launch_copy2d(s, x_T, D, x_out, D, n, D));
+  else OSD_HIP(launch_fill_randn(s, x_out, D, n, D, seed, (uint32_t)row_offset, (uint32_t)T, TAG_POSTERIOR));
+
+  // ---- sync words: [status x4 | cu arrivals x2048 | progress x n_tiles], zeroed before every chain ----
+  const int64_t words = 4 + 2048 + ((n_tiles + 3) / 4) * 4;
+  if (h->chain_sync_words < words) {
+    if (h->chain_sync) { OSD_HIP(hipStreamSynchronize(s)); OSD_HIP(hipFree(h->chain_sync)); h->chain_sync = nullptr; h->chain_sync_words = 0; }
+    if (hipMalloc((void**)&h->chain_sync, (size_t)words * 4) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc failed"); return OSD_ENOMEM; }
+    h->chain_sync_words = words;
+  }
+  OSD_HIP(hipMemsetAsync(h->chain_sync, 0, (size_t)words * 4, s));
+  ca.status = h->chain_sync;
+  ca.cu_arrivals = h->chain_stagger > 0 ? h->chain_sync + 4 : nullptr;
+  ca.progress = h->chain_sync + 4 + 2048;
+  ca.stagger = h->chain_stagger;
+  ca.spin_budget = 500000000ull;            // 5 s of s_memrealtime ticks: a unit takes milliseconds
+
+  // ---- layer table ----
+  const ParamMap& pm = a.pm;
+  int nl = 0;
+  {
+    ChainLayer& L = ca.L[nl++];
+    L.A = h->w_in_packed; L.lda = h->w_in_ld; L.K = D; L.K0 = D; L.F = H0;
+    L.in0 = -1; L.ld0 = D; L.in1 = 0; L.ld1 = 0; L.out = o_h0; L.ldo = H0; L.kind = CK_INPUT;
+    L.bias = h->params[pm.in_b]; L.gamma = nullptr; L.beta = nullptr;
+  }
+  int cur = o_h0, cur_w = H0;
+  for (int b = 0; b < a.n_blocks; ++b) {
+    const LayerDesc& l1 = a.layers[2 * b];
+    const LayerDesc& l2 = a.layers[2 * b + 1];
+    ChainLayer& A1 = ca.L[nl++];
+    A1.A = h->params[l1.w]; A1.lda = l1.K1 + l1.K2; A1.K = l1.K1 + l1.K2; A1.K0 = l1.K2 > 0 ? l1.K1 : l1.K1 + l1.K2; A1.F = l1.N;
+    A1.in0 = cur; A1.ld0 = cur_w; A1.in1 = 0; A1.ld1 = 0;
+    if (l1.K2 > 0) {
+      const int skip_block = a.n_enc - 1 - (b - a.n_enc - 1);      // LIFO: decoder j pops encoder n_enc-1-j
+      A1.in1 = o_out[skip_block]; A1.ld1 = a.block_out[skip_block];
+    }
+    A1.out = o_mid[b]; A1.ldo = l1.N; A1.kind = l1.gw == 64 ? CK_GN64 : CK_GN32;
+    A1.bias = h->params[l1.b]; A1.gamma = h->params[l1.gamma]; A1.beta = h->params[l1.beta];
+    ChainLayer& A2 = ca.L[nl++];
+    A2.A = h->params[l2.w]; A2.lda = l2.K1; A2.K = l2.K1; A2.K0 = l2.K1; A2.F = l2.N;
+    A2.in0 = o_mid[b]; A2.ld0 = l1.N; A2.in1 = 0; A2.ld1 = 0;
+    A2.out = o_out[b]; A2.ldo = l2.N; A2.kind = l2.gw == 64 ? CK_GN64 : CK_GN32;
+    A2.bias = h->params[l2.b]; A2.gamma = h->params[l2.gamma]; A2.beta = h->params[l2.beta];
+    cur = o_out[b]; cur_w = l2.N;
+  }
+  {
+    ChainLayer& L = ca.L[nl++];
+    L.A = h->params[pm.out_w]; L.lda = cur_w; L.K = cur_w; L.K0 = cur_w; L.F = D;
+    L.in0 = cur; L.ld0 = cur_w; L.in1 = 0; L.ld1 = 0; L.out = 0; L.ldo = 0; L.kind = CK_POST;
+    L.bias = h->params[pm.out_b]; L.gamma = nullptr; L.beta = nullptr;
+  }
+  ca.n_layers = nl;
+  ca.x = x_out; ca.D = D; ca.n = (int)n; ca.n_tiles = n_tiles;
+  ca.cproj = cw.cproj; ca.ldc = H0; ca.temb = h->d_temb; ca.ldt = H0; ca.coef = h->d_coef;
+  ca.z = noises; ca.ldzz = D; ca.z_step_stride = (long long)n * D; ca.z_t_first = T - 1;
+  ca.seed = seed; ca.row_offset = (uint32_t)row_offset;
+  ca.mut_mask = mut_mask_out; ca.mutation_dim = h->cfg.mutation_dim;
+
+  // ---- launches: the whole chain in one, or segments of chain_steps_per_launch steps (progress carries over) ----
+  const int seg = h->chain_steps_per_launch > 0 ? h->chain_steps_per_launch : T;
+  for (int done = 0; done < T; done += seg) {
+    ca.t_first = T - 1 - done;
+    ca.n_steps = std::min(seg, T - done);
+    ca.base_done = (unsigned)done;
+    if (done > 0 && ca.cu_arrivals) OSD_HIP(hipMemsetAsync(ca.cu_arrivals, 0, 2048 * 4, s));
+    hipLaunchKernelGGL(chain_kernel, dim3(grid), dim3(NTHREADS), CHAIN_LDS_BYTES, s, ca);
+    OSD_HIP(hipGetLastError());
+  }
+  h->chain_pending = true;
+  return OSD_OK;
+}
+
+void chain_free(osd_handle* h) {
+  hipError_t e = hipSuccess;
+  if (h->chain_ws) e = hipFree(h->chain_ws);
+  if (h->chain_cond) e = hipFree(h->chain_cond);
+  if (h->chain_sync) e = hipFree(h->chain_sync);
+  (void)e;
+  h->chain_ws = h->chain_cond = nullptr;
+  h->chain_sync = nullptr;
+}
+
+}  // namespace osd

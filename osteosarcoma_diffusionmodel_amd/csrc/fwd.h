@@ -23,6 +23,13 @@ int refresh_derived(osd_handle* h, hipStream_t s);
 GemmArgs output_proj_args(osd_handle* h, const FwdWs& ws, int64_t n);
 int check_ready(osd_handle* h);
 int check_rows(int64_t n);
+// chain.hip
+bool chain_supported(const Arch& a);
+int chain_pick_engine(osd_handle* h, int64_t n, int flags);
+int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, const float* noises, uint64_t seed, int64_t row_offset,
+              float* x_out, float* mut_mask_out);
+int chain_check_status(osd_handle* h);
+void chain_free(osd_handle* h);
 int check_row_offset(int64_t row_offset, int64_t n);
 int sanitize_t(osd_handle* h, hipStream_t s, const int32_t* t_index, int64_t n, const int** out);
 

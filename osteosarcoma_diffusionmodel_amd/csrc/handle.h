@@ -16,6 +16,7 @@ void set_error(const char* fmt, ...);
     hipError_t e__ = (call);                                                             \
     if (e__ != hipSuccess) {                                                             \
       ::osd::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      (void)hipGetLastError(); /* reported: do not let it resurface in a later launch check */            \
       return OSD_EHIP;                                                                   \
     }                                                                                    \
   } while (0)
@@ -113,6 +114,16 @@ struct osd_handle {
   osd::ConsPlan cons;
   double w_pathway = 0.0, w_mutexpr = 0.0;
   float* parts_dev = nullptr;
+  // persistent reverse-chain kernel (chain.h / chain.hip)
+  int sampler = 0;                   // osd_set_option("sampler"): 0 auto, 1 chain kernel whenever the architecture allows, 2 per-layer kernels
+  int chain_grid = 0;                // 0 = min(row tiles, resident slots); > 0 caps the workgroup count (tests: force cross-workgroup hand-offs)
+  int chain_steps_per_launch = 0;    // 0 = the whole chain in one launch
+  int chain_stagger = 30000;         // shader cycles between the starts of the two workgroups of a CU (0 = off)
+  float* chain_ws = nullptr; int64_t chain_ws_floats = 0;
+  float* chain_cond = nullptr; int64_t chain_cond_floats = 0;
+  unsigned* chain_sync = nullptr; int64_t chain_sync_words = 0;
+  bool chain_pending = false;        // a chain was launched whose status word has not been read yet
+  int last_engine = 0;               // engine of the most recent osd_sample_chain (0 per-layer, 1 chain kernel)
   // osd_profile_step: when non-null, run_trunk records prof_events[prof_i++] after every launch
   std::vector<hipEvent_t>* prof_events = nullptr;
   int prof_i = 0;

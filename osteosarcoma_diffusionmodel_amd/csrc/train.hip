@@ -97,7 +97,7 @@ static int ensure_train_ws(osd_handle* h, hipStream_t s, int64_t n, const ConsPl
   if (h->train_arena_floats < need) {
     if (h->train_arena) { OSD_HIP(hipStreamSynchronize(s)); OSD_HIP(hipFree(h->train_arena)); h->train_arena = nullptr; h->train_arena_floats = 0; }
     void* p = nullptr;
-    if (hipMalloc(&p, (size_t)need * 4) != hipSuccess) { set_error("hipMalloc of %lld bytes failed", (long long)need * 4); return OSD_ENOMEM; }
+    if (hipMalloc(&p, (size_t)need * 4) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc of %lld bytes failed", (long long)need * 4); return OSD_ENOMEM; }
     h->train_arena = (float*)p;
     h->train_arena_floats = need;
   }

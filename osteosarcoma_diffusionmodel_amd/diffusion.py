@@ -229,6 +229,13 @@ class BiologyAwareDiffusionModel(nn.Module):
         self.sample_chunk_rows: Optional[int] = None
         self.sample_streams: Optional[int] = None
         self.use_graph: bool = True
+        # reverse-chain engine: "auto" (library default: the persistent chain kernel for large eval-mode batches of a
+        # 256/512-wide architecture, else the per-layer kernels), "chain", "graph" (per-layer kernels; hipGraph iff use_graph)
+        self.sampler: str = "auto"
+        self.chain_grid: Optional[int] = None             # cap on the chain kernel's workgroups (tests)
+        self.chain_steps_per_launch: Optional[int] = None
+        self.chain_stagger: Optional[int] = None
+        self.last_sampler: Optional[str] = None           # engine the most recent sample() ran on
         self.train_streams: Optional[int] = None      # 1 = whole backward on one stream, 2 (library default) = weight gradients on a side stream
         # optional constraint losses (set_constraints); None = the reference's eps-MSE only
         self._constraints = None
@@ -321,6 +328,15 @@ class BiologyAwareDiffusionModel(nn.Module):
             L.check(L.lib().osd_set_option(eng.handle, b"n_streams", int(self.sample_streams)))
         if self.train_streams:
             L.check(L.lib().osd_set_option(eng.handle, b"train_streams", int(self.train_streams)))
+        try:
+            mode = {"auto": 0, "chain": 1, "graph": 2, "layers": 2}[self.sampler]
+        except KeyError:
+            raise ValueError(f"sampler must be 'auto', 'chain' or 'graph', got {self.sampler!r}")
+        L.check(L.lib().osd_set_option(eng.handle, b"sampler", mode))
+        for name, val in (("chain_grid", self.chain_grid), ("chain_steps_per_launch", self.chain_steps_per_launch),
+                          ("chain_stagger", self.chain_stagger)):
+            if val is not None:
+                L.check(L.lib().osd_set_option(eng.handle, name.encode(), int(val)))
         return eng
 
     def _prep(self, t: torch.Tensor, cols: Optional[int] = None, name: str = "tensor") -> torch.Tensor:
@@ -445,6 +461,10 @@ class BiologyAwareDiffusionModel(nn.Module):
         if seed is None:
             seed = _draw_seed()
         flags = self._flags() | (L.OSD_F_GRAPH if self.use_graph else 0)
+        chain = L.lib().osd_sample_engine(eng.handle, n, flags) == 1
+        self.last_sampler = "chain" if chain else "graph"
+        if chain:
+            flags |= L.OSD_F_SYNC       # the chain kernel's bounded waits report through a status word: read it before returning
         L.check(L.lib().osd_sample_chain(eng.handle, L.ptr(conditions), n, L.ptr(xT), L.ptr(zs), seed, int(row_offset),
                                          L.ptr(out), L.ptr(mask), flags))
         if return_mutation_mask:

@@ -1,0 +1,102 @@
+"""GPU: the persistent reverse-chain kernel (csrc/chain.h) -- every layer and every step of sample() in one launch, row
+tiles handed between workgroups through agent-scope release / acquire -- against the per-layer kernels (bitwise: same
+tile loop, same epilogues, same Philox addressing) and against the CPU oracle (models/diffusion.py:382-449).
+
+The workgroup count is capped (``chain_grid``) below the tile count so that every step of a tile runs on a different
+workgroup than the previous one, i.e. every x_t crosses a hand-off; row counts are ragged (last tile partly filled)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffusion_oracle as O
+from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel, _lib as L
+from helpers import FULL, FULL_H, assert_close, config
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(T, hidden=FULL_H, seed=0, **dims):
+    torch.manual_seed(seed)
+    d = dict(FULL)
+    d.update(dims)
+    m = BiologyAwareDiffusionModel(config=config(hidden, T=T), **d).cuda().eval()
+    gen = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():                  # non-trivial GroupNorm affine
+        for k, p in m.named_parameters():
+            if k.endswith((".1.weight", ".5.weight")):
+                p.copy_((1 + 0.2 * torch.randn(p.shape, generator=gen)).cuda())
+            if k.endswith((".1.bias", ".5.bias")):
+                p.copy_((0.1 * torch.randn(p.shape, generator=gen)).cuda())
+    return m
+
+
+def _run(m, cond, n, sampler, **kw):
+    m.sampler = sampler
+    out, mask = m.sample(cond, n, return_mutation_mask=True, **kw)
+    assert m.last_sampler == ("chain" if sampler == "chain" else "graph")
+    return out, mask
+
+
+@pytest.mark.parametrize("n,grid", [(1000, 3), (128, 1), (1337, 5), (4096, 0)])
+def test_chain_kernel_equals_per_layer_kernels_bitwise(n, grid):
+    T = 12
+    m = _model(T)
+    cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(3)).cuda()
+    ref, ref_mask = _run(m, cond, n, "graph", seed=77, row_offset=5)
+    m.chain_grid = grid
+    out, mask = _run(m, cond, n, "chain", seed=77, row_offset=5)
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, ref), f"max|d| = {(out - ref).abs().max().item():.3e} of {ref.abs().max().item():.3e}"
+    assert torch.equal(mask, ref_mask)
+    # segmented launches (progress carries over kernel boundaries) and no stagger: same bits
+    m.chain_steps_per_launch, m.chain_stagger = 5, 0
+    out2, mask2 = _run(m, cond, n, "chain", seed=77, row_offset=5)
+    assert torch.equal(out2, ref) and torch.equal(mask2, ref_mask)
+
+
+def test_chain_kernel_vs_oracle_with_injected_draws():
+    """300 rows (two full tiles + 44 rows), T = 30, the oracle's x_T and z injected; two workgroups alternate over three
+    tiles.  Chain tolerance 5e-5 * max|ref| (the un-clamped x0_hat amplifies the first steps)."""
+    T, n = 30, 300
+    m = _model(T, seed=4)
+    gen = torch.Generator().manual_seed(9)
+    cond = torch.randn(n, 3, generator=gen)
+    x_T = torch.randn(n, 2000, generator=gen)
+    zs = torch.randn(T - 1, n, 2000, generator=gen)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items() if k.startswith(("condition_embed", "unet"))}
+    bufs = O.schedule_buffers("cosine", T)
+    ref = O.sample(sd, bufs, cond, x_T, lambda t: zs[T - 1 - t], 3, 128)
+    m.chain_grid = 2
+    out, mask = _run(m, cond.cuda(), n, "chain", x_T=x_T.cuda(), noise=zs.cuda())
+    assert_close(out, ref, 5e-5, atol=1e-5, what="chain kernel vs oracle")
+    refm = (ref[:, :50] > 0.5).float()
+    near = (ref[:, :50] - 0.5).abs() <= 5e-5 * ref.abs().max() + 1e-5
+    assert ((mask.cpu() != refm) & ~near).sum().item() == 0
+
+
+def test_chain_kernel_other_widths_and_fallbacks():
+    """512-wide first layer, 512/256 blocks (both GroupNorm widths in other positions); architectures or modes outside the
+    chain kernel fall back to the per-layer kernels without being asked."""
+    T, n = 8, 700
+    m = _model(T, hidden=[512, 256, 512], seed=2)
+    cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    ref, _ = _run(m, cond, n, "graph", seed=5)
+    m.chain_grid = 4
+    out, _ = _run(m, cond, n, "chain", seed=5)
+    assert torch.equal(out, ref)
+    # dropout active (train-mode sampling, as the reference's __main__ smoke test does): per-layer kernels
+    m.train()
+    m.sampler = "chain"
+    m.sample(cond, n, seed=5)
+    assert m.last_sampler == "graph"
+    # a width the chain kernel does not cover
+    m2 = _model(T, hidden=[256, 128, 256], seed=2)
+    m2.sampler = "chain"
+    m2.sample(cond, n, seed=5)
+    assert m2.last_sampler == "graph"
+    # auto: small batches stay on the per-layer kernels, config-3-sized ones take the chain kernel
+    m3 = _model(T)
+    eng = m3._engine()
+    assert L.lib().osd_sample_engine(eng.handle, 4096, 0) == 0
+    assert L.lib().osd_sample_engine(eng.handle, 100_000, 0) == 1
+    assert L.lib().osd_sample_engine(eng.handle, 100_000, L.OSD_F_TRAIN_MODE) == 0
