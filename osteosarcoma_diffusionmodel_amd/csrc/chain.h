@@ -85,6 +85,63 @@ __device__ __forceinline__ bool chain_wait(const unsigned* word, unsigned want, 
   }
 }
 
+// Linear -> GroupNorm(8) -> SiLU epilogue on a full private tile: the arithmetic of EpiGnSilu<GW, false>::apply, operation
+// for operation (the two engines must agree bitwise), but the per-feature parameters are fetched where they are used
+// instead of being held in 96 registers from before the K loop -- the chain kernel carries its tile / layer / unit state
+// on top of the accumulators and would spill otherwise.  `out` has all 128 rows of the tile (no row guard).
+template <int GW, int NFB, int NPB>
+__device__ __forceinline__ void chain_gn_silu(f32x16 (&acc)[NFB][NPB], const float* bias, const float* gamma, const float* beta,
+                                              float* out, int ldo, int fw, int pw, int lane, int F) {
+  static_assert(GW >= 8 && NFB * 32 >= GW, "wave must own whole groups");
+  constexpr int RPG = GW / 2;                 // registers of one group in this lane
+  constexpr int NG = NFB * 16 / RPG;
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bv = ldq<true>(bias, fw + 32 * fb + 8 * q + 4 * h, F);
+#pragma unroll
+      for (int pb = 0; pb < NPB; ++pb) {
+        acc[fb][pb][4 * q] += bv.x; acc[fb][pb][4 * q + 1] += bv.y;
+        acc[fb][pb][4 * q + 2] += bv.z; acc[fb][pb][4 * q + 3] += bv.w;
+      }
+    }
+#pragma unroll
+  for (int pb = 0; pb < NPB; ++pb) {
+    float mean[NG], rstd[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < RPG; ++j) { const int Li = g * RPG + j; s += acc[Li / 16][pb][Li % 16]; }
+      s += swap_halves(s);
+      const float m = s * (1.0f / GW);
+      float qs = 0.f;
+#pragma unroll
+      for (int j = 0; j < RPG; ++j) { const int Li = g * RPG + j; const float d = acc[Li / 16][pb][Li % 16] - m; qs = fmaf(d, d, qs); }
+      qs += swap_halves(qs);
+      mean[g] = m;
+      rstd[g] = 1.0f / sqrtf(qs * (1.0f / GW) + GN_EPS);
+    }
+    float* orow = out + (size_t)(pw + 32 * pb + l31) * ldo;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = fw + 32 * fb + 8 * q + 4 * h;
+        const int g = (fb * 16 + 4 * q) / RPG;
+        const float4 gv = ldq<true>(gamma, f, F), bev = ldq<true>(beta, f, F);
+        float4 y;
+        y.x = silu_f(fmaf((acc[fb][pb][4 * q] - mean[g]) * rstd[g], gv.x, bev.x));
+        y.y = silu_f(fmaf((acc[fb][pb][4 * q + 1] - mean[g]) * rstd[g], gv.y, bev.y));
+        y.z = silu_f(fmaf((acc[fb][pb][4 * q + 2] - mean[g]) * rstd[g], gv.z, bev.z));
+        y.w = silu_f(fmaf((acc[fb][pb][4 * q + 3] - mean[g]) * rstd[g], gv.w, bev.w));
+        stq<true>(orow, f, F, y);
+      }
+  }
+}
+
 typedef Tile<128, 128, 64, 64> ChainTile;
 constexpr int CHAIN_LDS_BYTES = GldsTile<ChainTile>::LDS_BYTES + 16;
 
@@ -251,48 +308,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
         }
 
         // ---- epilogue (the per-layer kernels' own, on local row coordinates of the tile) ----
-        // per-feature parameters are fetched here, not ahead of the K loop: 96 registers held across the loop would push the
-        // kernel past 256 VGPRs, and the one L2 latency falls into the co-resident workgroup's MFMA time
         const int fw = f0 + wf;
-        float4 p_bias[T::NFB][4], p_gamma[T::NFB][4], p_beta[T::NFB][4];
-        const bool is_gn = L.kind == CK_GN32 || L.kind == CK_GN64;
-#pragma unroll
-        for (int fb = 0; fb < T::NFB; ++fb)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int f = fw + 32 * fb + 8 * q + 4 * h;
-            p_bias[fb][q] = ldq<true>(L.bias, f, F);
-            if (is_gn) { p_gamma[fb][q] = ldq<true>(L.gamma, f, F); p_beta[fb][q] = ldq<true>(L.beta, f, F); }
-            else { p_gamma[fb][q] = make_float4(1.f, 1.f, 1.f, 1.f); p_beta[fb][q] = make_float4(0.f, 0.f, 0.f, 0.f); }
-          }
-        if (L.kind == CK_GN64 || L.kind == CK_GN32) {
-          float* outp = ws + L.out;
-          if (L.kind == CK_GN64) {
-            typedef EpiGnSilu<64, false> E;
-            E::Args ea{L.bias, L.gamma, L.beta, outp, L.ldo, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, 0, 0, 0, 0, nullptr};
-            E::Pre<T::NFB> pre;
-#pragma unroll
-            for (int fb = 0; fb < T::NFB; ++fb)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { pre.bias[fb][q] = p_bias[fb][q]; pre.gamma[fb][q] = p_gamma[fb][q]; pre.beta[fb][q] = p_beta[fb][q]; }
-            E::apply<T::NFB, T::NPB, true>(acc, ea, pre, fw, wp, lane, F, T::BP);
-          } else {
-            typedef EpiGnSilu<32, false> E;
-            E::Args ea{L.bias, L.gamma, L.beta, outp, L.ldo, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, 0, 0, 0, 0, nullptr};
-            E::Pre<T::NFB> pre;
-#pragma unroll
-            for (int fb = 0; fb < T::NFB; ++fb)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { pre.bias[fb][q] = p_bias[fb][q]; pre.gamma[fb][q] = p_gamma[fb][q]; pre.beta[fb][q] = p_beta[fb][q]; }
-            E::apply<T::NFB, T::NPB, true>(acc, ea, pre, fw, wp, lane, F, T::BP);
-          }
+        if (L.kind == CK_GN64) {
+          chain_gn_silu<64, T::NFB, T::NPB>(acc, L.bias, L.gamma, L.beta, ws + L.out, L.ldo, fw, wp, lane, F);
+        } else if (L.kind == CK_GN32) {
+          chain_gn_silu<32, T::NFB, T::NPB>(acc, L.bias, L.gamma, L.beta, ws + L.out, L.ldo, fw, wp, lane, F);
         } else if (L.kind == CK_INPUT) {
           EpiInput::Args ea{L.bias, a.temb, a.ldt, nullptr, nullptr, t, a.cproj + (size_t)p0 * a.ldc, a.ldc, ws + L.out, L.ldo};
-          EpiInput::Pre<T::NFB> pre;
-#pragma unroll
-          for (int fb = 0; fb < T::NFB; ++fb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pre.bias[fb][q] = p_bias[fb][q];
+          const EpiInput::Pre<T::NFB> pre = EpiInput::prefetch<T::NFB, true>(ea, fw, lane, F);
           // rows beyond P hold a clamped copy of the last valid row: computed and stored to the private tile like the others (the
           // host pads cproj to whole tiles), never published (the posterior epilogue stores rows < P only)
           EpiInput::apply<T::NFB, T::NPB, true>(acc, ea, pre, fw, wp, lane, F, T::BP);
@@ -305,12 +328,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
           ea.z = a.z ? a.z + (size_t)p0 * a.ldzz : nullptr; ea.ldzz = a.ldzz; ea.z_step_stride = a.z_step_stride; ea.t_first = a.z_t_first;
           ea.seed = a.seed; ea.row_offset = a.row_offset + (uint32_t)p0;
           ea.mut_mask = a.mut_mask ? a.mut_mask + (size_t)p0 * a.mutation_dim : nullptr; ea.mutation_dim = a.mutation_dim;
-          EpiPosterior::Pre<T::NFB> pre;
-#pragma unroll
-          for (int fb = 0; fb < T::NFB; ++fb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pre.bias[fb][q] = p_bias[fb][q];
-          EpiPosterior::apply<T::NFB, T::NPB, true>(acc, ea, pre, fw, wp, lane, F, P);
+          const EpiPosterior::Pre<T::NFB> pre = EpiPosterior::prefetch<T::NFB, true>(ea, fw, lane, F);
+          EpiPosterior::apply<T::NFB, T::NPB, true, NoSync, false>(acc, ea, pre, fw, wp, lane, F, P);
         }
         // every wave's stores have left before any wave stages the next tile's operands (which may be this output)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

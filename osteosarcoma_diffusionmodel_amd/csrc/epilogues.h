@@ -290,7 +290,9 @@ struct EpiPosterior {
       for (int q = 0; q < 4; ++q) r.bias[fb][q] = ldq<FAST>(a.bias, fw + 32 * fb + 8 * q + 4 * h, F);
     return r;
   }
-  template <int NFB, int NPB, bool FAST, class Sync = NoSync>
+  // WIDE: every x_t quad of the wave's tile is requested before the first one is used (one latency, not sixteen; 64
+  // registers).  !WIDE (the chain kernel, which has fewer registers to spare): the four quads of one 32 x 32 block at a time.
+  template <int NFB, int NPB, bool FAST, class Sync = NoSync, bool WIDE = true>
   static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P,
                                                Sync&& sync = Sync()) {
     const int l31 = lane & 31, h = lane >> 5;
@@ -298,39 +300,50 @@ struct EpiPosterior {
     const float* c = a.coef + 4 * t;
     const float cA = c[0], cB = c[1], cC = c[2];
     const float* zbase = a.z ? a.z + (long long)(a.t_first - t) * a.z_step_stride : nullptr;
-    // every x_t quad of the wave's tile is requested before the first one is used (one latency, not sixteen)
-    float4 xq[NFB][NPB][4];
-    OSD_FOR_QUADS(fb, pb, q) {
-      const int p = pw + 32 * pb + l31;
-      xq[fb][pb][q] = ldq<FAST>(a.xin + (size_t)(p < P ? p : P - 1) * a.ldx, fw + 32 * fb + 8 * q + 4 * h, F);
-    }
-    OSD_FOR_QUADS(fb, pb, q) {
-      const int f = fw + 32 * fb + 8 * q + 4 * h;
-      const int p = pw + 32 * pb + l31;
-      const int pc = p < P ? p : P - 1;
-      const bool ok = p < P && f < F;
-      const float4 bv = pre.bias[fb][q];
-      const float4 x = xq[fb][pb][q];
-      const float e[4] = {acc[fb][pb][4 * q] + bv.x, acc[fb][pb][4 * q + 1] + bv.y, acc[fb][pb][4 * q + 2] + bv.z, acc[fb][pb][4 * q + 3] + bv.w};
-      const float xv[4] = {x.x, x.y, x.z, x.w};
-      float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t > 0) {
-        if (zbase) zz = ldq<FAST>(zbase + (size_t)pc * a.ldzz, f, F);
-        else zz = randn4(a.seed, a.row_offset + (uint32_t)p, (uint32_t)(f >> 2), (uint32_t)t, TAG_POSTERIOR);
+    float4 xq[WIDE ? NFB : 1][WIDE ? NPB : 1][4];
+    if constexpr (WIDE) {
+      OSD_FOR_QUADS(fb, pb, q) {
+        const int p = pw + 32 * pb + l31;
+        xq[fb][pb][q] = ldq<FAST>(a.xin + (size_t)(p < P ? p : P - 1) * a.ldx, fw + 32 * fb + 8 * q + 4 * h, F);
       }
-      const float zv[4] = {zz.x, zz.y, zz.z, zz.w};
-      float o[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = fmaf(cA, xv[r], fmaf(cB, e[r], cC * zv[r]));
-      if (t == 0 && a.mut_mask && ok && f < a.mutation_dim) {
-        float* mrow = a.mut_mask + (size_t)p * a.mutation_dim;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (f + r < a.mutation_dim) mrow[f + r] = (o[r] > 0.5f) ? 1.0f : 0.0f;
-      }
-      if (p < P) stq<FAST>(a.xout + (size_t)pc * a.ldo, f, F, make_float4(o[0], o[1], o[2], o[3]));
-      sync.tick();
     }
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int pb = 0; pb < NPB; ++pb) {
+        const int p = pw + 32 * pb + l31;
+        const int pc = p < P ? p : P - 1;
+        if constexpr (!WIDE) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xq[0][0][q] = ldq<FAST>(a.xin + (size_t)pc * a.ldx, fw + 32 * fb + 8 * q + 4 * h, F);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int f = fw + 32 * fb + 8 * q + 4 * h;
+          const bool ok = p < P && f < F;
+          const float4 bv = pre.bias[fb][q];
+          const float4 x = xq[WIDE ? fb : 0][WIDE ? pb : 0][q];
+          const float e[4] = {acc[fb][pb][4 * q] + bv.x, acc[fb][pb][4 * q + 1] + bv.y, acc[fb][pb][4 * q + 2] + bv.z, acc[fb][pb][4 * q + 3] + bv.w};
+          const float xv[4] = {x.x, x.y, x.z, x.w};
+          float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (t > 0) {
+            if (zbase) zz = ldq<FAST>(zbase + (size_t)pc * a.ldzz, f, F);
+            else zz = randn4(a.seed, a.row_offset + (uint32_t)p, (uint32_t)(f >> 2), (uint32_t)t, TAG_POSTERIOR);
+          }
+          const float zv[4] = {zz.x, zz.y, zz.z, zz.w};
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = fmaf(cA, xv[r], fmaf(cB, e[r], cC * zv[r]));
+          if (t == 0 && a.mut_mask && ok && f < a.mutation_dim) {
+            float* mrow = a.mut_mask + (size_t)p * a.mutation_dim;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (f + r < a.mutation_dim) mrow[f + r] = (o[r] > 0.5f) ? 1.0f : 0.0f;
+          }
+          if (p < P) stq<FAST>(a.xout + (size_t)pc * a.ldo, f, F, make_float4(o[0], o[1], o[2], o[3]));
+          sync.tick();
+        }
+      }
   }
 };
 
