@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=0)
     ap.add_argument("--sampler", choices=["auto", "chain", "graph"], default="auto",
                     help="reverse-chain engine: persistent chain kernel, per-layer kernels under a hipGraph, or the library default")
+    ap.add_argument("--chain-stagger", type=int, default=-1, help="chain kernel: cycles between the two workgroups of a CU (default: library)")
+    ap.add_argument("--chain-steps-per-launch", type=int, default=-1)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-full-sample", action="store_true", help="skip the un-extrapolated CPU sample(N=1024, T=1000) leg")
@@ -275,6 +277,10 @@ def main():
     model.use_graph = not args.no_graph
     if args.sampler != "auto":
         model.sampler = args.sampler
+    if args.chain_stagger >= 0:
+        model.chain_stagger = args.chain_stagger
+    if args.chain_steps_per_launch >= 0:
+        model.chain_steps_per_launch = args.chain_steps_per_launch
 
     n = args.patients
     offset = rank * n                          # global row ids: results independent of the GPU count
