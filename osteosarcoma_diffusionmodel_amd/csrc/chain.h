@@ -62,6 +62,8 @@ struct ChainArgs {
   unsigned* cu_arrivals;                     // [2048] zeroed per launch; null = no stagger
   int stagger;                               // shader cycles the second workgroup of a CU waits before its first unit
   unsigned long long spin_budget;            // s_memrealtime ticks (100 MHz) a dependency wait may take
+  unsigned long long* stamps;                // diagnostic (null in production): per workgroup 8 counters of shader cycles --
+                                             // dependency wait, tile prologue, K loop, epilogue + drain, whole kernel, units run
 };
 
 typedef __attribute__((address_space(1))) unsigned gu32;
@@ -199,8 +201,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
     }
   }
 
+  unsigned long long c_dep = 0, c_pro = 0, c_k = 0, c_epi = 0, c_units = 0;
+  const unsigned long long c_start = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
   const long long n_units = (long long)a.n_tiles * a.n_steps;
   for (long long u = blockIdx.x; u < n_units; u += gridDim.x) {
+    const unsigned long long td0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
     const int tile = (int)(u % a.n_tiles);
     const int si = (int)(u / a.n_tiles);
     const int t = a.t_first - si;
@@ -220,6 +225,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
     __syncthreads();
     const int go = s_flag;
     if (!go) return;                      // uniform over the workgroup: every wave leaves
+    if (a.stamps) { c_dep += __builtin_amdgcn_s_memtime() - td0; ++c_units; }
 
     for (int l = 0; l < a.n_layers; ++l) {
       const ChainLayer& L = a.L[l];
@@ -252,11 +258,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
             glds16(bb + (size_t)rg * ld + k, __builtin_amdgcn_readfirstlane(lb + (unsigned)jb * 4096u));
           }
         };
+        const unsigned long long tt0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) stage(0, As0, Bs0, j);
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the asm DMAs are invisible to hipcc's counters
         __syncthreads();
+        const unsigned long long tt1 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
 
         f32x16 acc[T::NFB][T::NPB];
 #pragma unroll
@@ -308,6 +316,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
         }
 
         // ---- epilogue (the per-layer kernels' own, on local row coordinates of the tile) ----
+        const unsigned long long tt2 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
         const int fw = f0 + wf;
         if (L.kind == CK_GN64) {
           chain_gn_silu<64, T::NFB, T::NPB>(acc, L.bias, L.gamma, L.beta, ws + L.out, L.ldo, fw, wp, lane, F);
@@ -334,6 +343,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
         // every wave's stores have left before any wave stages the next tile's operands (which may be this output)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (a.stamps) {
+          const unsigned long long tt3 = __builtin_amdgcn_s_memtime();
+          c_pro += tt1 - tt0; c_k += tt2 - tt1; c_epi += tt3 - tt2;
+        }
       }
     }
 
@@ -343,6 +356,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // hipcc may drop the fence's own wait (Guideline 16, pitfall 12)
       st_relaxed_agent(a.progress + tile, a.base_done + (unsigned)si + 1u);
     }
+  }
+  if (a.stamps && leader) {
+    unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+    o[0] = c_dep; o[1] = c_pro; o[2] = c_k; o[3] = c_epi; o[4] = __builtin_amdgcn_s_memtime() - c_start; o[5] = c_units;
   }
 }
 

@@ -130,6 +130,7 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
   ca.cu_arrivals = h->chain_stagger > 0 ? h->chain_sync + 4 : nullptr;
   ca.progress = h->chain_sync + 4 + 2048;
   ca.stagger = h->chain_stagger;
+  ca.stamps = h->chain_stamps;
   ca.spin_budget = 500000000ull;            // 5 s of s_memrealtime ticks: a unit takes milliseconds
 
   // ---- layer table ----

@@ -262,3 +262,12 @@ extern "C" int osd_dbg_stamp_gn(osd_handle* h, const float* x, int K, const floa
   OSD_HIP(launch_gn_silu(h->stream, g, N / 8, ga));
   return OSD_OK;
 }
+
+// diagnostic: where a workgroup of the persistent chain kernel spends its cycles.  `buf` (device, 8 x u64 per workgroup, >= 512
+// workgroups) receives, for the chain runs that follow, dependency wait / tile prologue / K loop / epilogue+drain / kernel
+// total / units; pass null to switch the stamps off again.
+extern "C" int osd_dbg_chain_stamps(osd_handle* h, unsigned long long* buf) {
+  if (!h) return OSD_EINVAL;
+  h->chain_stamps = buf;
+  return OSD_OK;
+}

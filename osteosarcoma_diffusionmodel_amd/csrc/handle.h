@@ -123,6 +123,7 @@ struct osd_handle {
   float* chain_cond = nullptr; int64_t chain_cond_floats = 0;
   unsigned* chain_sync = nullptr; int64_t chain_sync_words = 0;
   bool chain_pending = false;        // a chain was launched whose status word has not been read yet
+  unsigned long long* chain_stamps = nullptr;   // diagnostic builds (csrc/diag): device buffer of 8 counters per workgroup, else null
   int last_engine = 0;               // engine of the most recent osd_sample_chain (0 per-layer, 1 chain kernel)
   // osd_profile_step: when non-null, run_trunk records prof_events[prof_i++] after every launch
   std::vector<hipEvent_t>* prof_events = nullptr;

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Diagnostic (needs `make DIAG=1`): cycle shares of the persistent chain kernel's workgroups at the config-3 shape."""
+import ctypes as C, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np, torch
+from bench import CONF, scenario_conditions
+from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel, _lib as L
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+stagger = int(sys.argv[3]) if len(sys.argv) > 3 else 30000
+conf = {"model": dict(CONF["model"])}; conf["model"]["diffusion"] = {"num_steps": steps, "beta_schedule": "cosine"}
+torch.manual_seed(0)
+m = BiologyAwareDiffusionModel(50, 1900, 50, 3, conf).cuda().eval()
+m.sampler, m.chain_stagger = "chain", stagger
+eng = m._engine()
+fn = L.lib().osd_dbg_chain_stamps; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p]
+buf = torch.zeros(1024 * 8, dtype=torch.int64, device="cuda")
+cond = scenario_conditions(n, 0).cuda()
+m.sample(cond, n, seed=1)                       # warm-up, unstamped
+L.check(fn(eng.handle, L.ptr(buf)))
+torch.cuda.synchronize(); import time; t0 = time.perf_counter()
+m.sample(cond, n, seed=2)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+s = buf.cpu().numpy().reshape(-1, 8); s = s[s[:, 5] > 0]
+tot = s[:, 4].astype(float)
+print(f"n={n} T={steps} stagger={stagger}: {dt*1e3:.1f} ms, {n/dt*steps/1000:.0f} patient-ksteps/s, {len(s)} workgroups, units/wg {s[:,5].min()}..{s[:,5].max()}")
+for name, col in (("dependency wait", 0), ("tile prologue (first DMA stage)", 1), ("K loop", 2), ("epilogue + drain", 3)):
+    sh = s[:, col] / tot
+    print(f"  {name:34s} {100*sh.mean():6.2f} %  (min {100*sh.min():.2f}, max {100*sh.max():.2f})   {s[:, col].mean()/s[:,5].mean():12.0f} cycles/unit")
+print(f"  kernel cycles / unit {tot.mean()/s[:,5].mean():.0f}; clock ~ {tot.mean()/dt/1e9:.2f} GHz")
