@@ -59,6 +59,7 @@ struct ChainArgs {
   float* mut_mask; int mutation_dim;
   unsigned* progress;                        // [n_tiles] steps completed per tile (monotonic over the launches of a chain)
   unsigned* status;                          // [0] CHAIN_OK / CHAIN_TIMEOUT
+  unsigned* queue;                           // [0] next unit of this launch (zeroed per launch): workgroups take units in global order
   unsigned* cu_arrivals;                     // [2048] zeroed per launch; null = no stagger
   int stagger;                               // shader cycles the second workgroup of a CU waits before its first unit
   unsigned long long spin_budget;            // s_memrealtime ticks (100 MHz) a dependency wait may take
@@ -92,26 +93,31 @@ __device__ __forceinline__ bool chain_wait(const unsigned* word, unsigned want, 
 // instead of being held in 96 registers from before the K loop -- the chain kernel carries its tile / layer / unit state
 // on top of the accumulators and would spill otherwise.  `out` has all 128 rows of the tile (no row guard).
 template <int GW, int NFB, int NPB>
-__device__ __forceinline__ void chain_gn_silu(f32x16 (&acc)[NFB][NPB], const float* bias, const float* gamma, const float* beta,
-                                              float* out, int ldo, int fw, int pw, int lane, int F) {
+__device__ __forceinline__ void chain_gn_silu(f32x16 (&acc)[NFB][NPB], const float* __restrict__ bias, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, float* __restrict__ out, int ldo, int fw, int pw, int lane, int F) {
   static_assert(GW >= 8 && NFB * 32 >= GW, "wave must own whole groups");
   constexpr int RPG = GW / 2;                 // registers of one group in this lane
   constexpr int NG = NFB * 16 / RPG;
   const int l31 = lane & 31, h = lane >> 5;
+  {
+    float4 bv[NFB][4];                        // one batch of loads, one L2 round trip
 #pragma unroll
-  for (int fb = 0; fb < NFB; ++fb)
+    for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 bv = ldq<true>(bias, fw + 32 * fb + 8 * q + 4 * h, F);
+      for (int q = 0; q < 4; ++q) bv[fb][q] = ldq<true>(bias, fw + 32 * fb + 8 * q + 4 * h, F);
 #pragma unroll
-      for (int pb = 0; pb < NPB; ++pb) {
-        acc[fb][pb][4 * q] += bv.x; acc[fb][pb][4 * q + 1] += bv.y;
-        acc[fb][pb][4 * q + 2] += bv.z; acc[fb][pb][4 * q + 3] += bv.w;
-      }
-    }
+    for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-  for (int pb = 0; pb < NPB; ++pb) {
-    float mean[NG], rstd[NG];
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb) {
+          acc[fb][pb][4 * q] += bv[fb][q].x; acc[fb][pb][4 * q + 1] += bv[fb][q].y;
+          acc[fb][pb][4 * q + 2] += bv[fb][q].z; acc[fb][pb][4 * q + 3] += bv[fb][q].w;
+        }
+  }
+  float mean[NPB][NG], rstd[NPB][NG];
+#pragma unroll
+  for (int pb = 0; pb < NPB; ++pb)
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       float s = 0.f;
@@ -123,31 +129,47 @@ __device__ __forceinline__ void chain_gn_silu(f32x16 (&acc)[NFB][NPB], const flo
 #pragma unroll
       for (int j = 0; j < RPG; ++j) { const int Li = g * RPG + j; const float d = acc[Li / 16][pb][Li % 16] - m; qs = fmaf(d, d, qs); }
       qs += swap_halves(qs);
-      mean[g] = m;
-      rstd[g] = 1.0f / sqrtf(qs * (1.0f / GW) + GN_EPS);
+      mean[pb][g] = m;
+      rstd[pb][g] = 1.0f / sqrtf(qs * (1.0f / GW) + GN_EPS);
     }
-    float* orow = out + (size_t)(pw + 32 * pb + l31) * ldo;
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb)
+  for (int fb = 0; fb < NFB; ++fb) {
+    float4 gv[4], bev[4];                     // this 32-feature block's affine parameters: one batch
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = fw + 32 * fb + 8 * q + 4 * h;
+      gv[q] = ldq<true>(gamma, f, F);
+      bev[q] = ldq<true>(beta, f, F);
+    }
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+      float* orow = out + (size_t)(pw + 32 * pb + l31) * ldo;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int f = fw + 32 * fb + 8 * q + 4 * h;
         const int g = (fb * 16 + 4 * q) / RPG;
-        const float4 gv = ldq<true>(gamma, f, F), bev = ldq<true>(beta, f, F);
+        const float m = mean[pb][g], r = rstd[pb][g];
         float4 y;
-        y.x = silu_f(fmaf((acc[fb][pb][4 * q] - mean[g]) * rstd[g], gv.x, bev.x));
-        y.y = silu_f(fmaf((acc[fb][pb][4 * q + 1] - mean[g]) * rstd[g], gv.y, bev.y));
-        y.z = silu_f(fmaf((acc[fb][pb][4 * q + 2] - mean[g]) * rstd[g], gv.z, bev.z));
-        y.w = silu_f(fmaf((acc[fb][pb][4 * q + 3] - mean[g]) * rstd[g], gv.w, bev.w));
+        y.x = silu_f(fmaf((acc[fb][pb][4 * q] - m) * r, gv[q].x, bev[q].x));
+        y.y = silu_f(fmaf((acc[fb][pb][4 * q + 1] - m) * r, gv[q].y, bev[q].y));
+        y.z = silu_f(fmaf((acc[fb][pb][4 * q + 2] - m) * r, gv[q].z, bev[q].z));
+        y.w = silu_f(fmaf((acc[fb][pb][4 * q + 3] - m) * r, gv[q].w, bev[q].w));
         stq<true>(orow, f, F, y);
       }
+    }
   }
 }
 
 typedef Tile<128, 128, 64, 64> ChainTile;
 constexpr int CHAIN_LDS_BYTES = GldsTile<ChainTile>::LDS_BYTES + 16;
 
-__global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
+// STAMP (diagnostic builds only, make DIAG=1): per-workgroup cycle counters; the product kernel carries none of that state.
+template <bool STAMP>
+__global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __restrict__ gp) {
+  // The argument block lives in device memory (uniform scalar loads).  Passed by value, hipcc hoists the loads of all ~60
+  // fields to the kernel entry and keeps them in SGPRs for the whole kernel; the spills of that end up in VGPRs.  Each phase
+  // therefore re-derives its pointer to the block through an empty asm, so a field is loaded where it is used.
+  const ChainArgs& a = *gp;
   typedef ChainTile T;
   typedef GldsTile<T> G;
   static_assert(G::NA == 4 && G::NB == 4, "staging below assumes 4 + 4 pieces per wave");
@@ -158,28 +180,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
   float* Bs1 = smem + 2 * G::A_ELEMS + G::B_ELEMS;
   // leader -> workgroup: 1 = go on, 0 = leave.  In the dynamic region behind the tiles: a static __shared__ would shift
   // the dynamic base off its 16-byte alignment (ds_read_b128 replays; Guideline 17)
-  volatile int& s_flag = *reinterpret_cast<volatile int*>(smem + 2 * (G::A_ELEMS + G::B_ELEMS));
+  volatile int& s_flag = *reinterpret_cast<volatile int*>(smem + 2 * (G::A_ELEMS + G::B_ELEMS));   // also carries the unit number
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wf = (wave / T::NWP) * T::WF;
   const int wp = (wave % T::NWP) * T::WP;
-  const int l31 = lane & 31, h = lane >> 5;
   const bool leader = tid == 0;
-
-  // staging geometry (tile independent): piece j of a wave moves rows 8 * (4 j + wave) .. + 7, 16 B per lane
-  int st_row[4], st_k4[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    st_row[j] = (j * 4 + wave) * 8 + (lane >> 3);
-    st_k4[j] = 4 * ((lane & 7) ^ ((st_row[j] >> 1) & 7));
-  }
-  int a_rd[T::NFB], a_sw[T::NFB], b_rd[T::NPB], b_sw[T::NPB];
-#pragma unroll
-  for (int fb = 0; fb < T::NFB; ++fb) { const int R = wf + 32 * fb + l31; a_rd[fb] = R * BK; a_sw[fb] = h ^ ((R >> 1) & 7); }
-#pragma unroll
-  for (int pb = 0; pb < T::NPB; ++pb) { const int R = wp + 32 * pb + l31; b_rd[pb] = R * BK; b_sw[pb] = h ^ ((R >> 1) & 7); }
 
   float* const ws = a.ws + (long long)blockIdx.x * a.ws_stride;
 
@@ -202,10 +210,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
   }
 
   unsigned long long c_dep = 0, c_pro = 0, c_k = 0, c_epi = 0, c_units = 0;
-  const unsigned long long c_start = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+  const unsigned long long c_start = STAMP ? __builtin_amdgcn_s_memtime() : 0;
   const long long n_units = (long long)a.n_tiles * a.n_steps;
-  for (long long u = blockIdx.x; u < n_units; u += gridDim.x) {
-    const unsigned long long td0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+  for (;;) {
+    const unsigned long long td0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+    // next unit, in global order: whoever is free takes it (a slow workgroup simply takes fewer), and every dependency of a
+    // unit was taken earlier by a workgroup that is running, so no wait can depend on a workgroup that is not resident
+    if (leader) s_flag = (int)atomicAdd(a.queue, 1u);
+    __syncthreads();
+    const long long u = (unsigned)s_flag;
+    __syncthreads();
+    if (u >= n_units) break;
     const int tile = (int)(u % a.n_tiles);
     const int si = (int)(u / a.n_tiles);
     const int t = a.t_first - si;
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
     __syncthreads();
     const int go = s_flag;
     if (!go) return;                      // uniform over the workgroup: every wave leaves
-    if (a.stamps) { c_dep += __builtin_amdgcn_s_memtime() - td0; ++c_units; }
+    if constexpr (STAMP) { c_dep += __builtin_amdgcn_s_memtime() - td0; ++c_units; }
 
     for (int l = 0; l < a.n_layers; ++l) {
       const ChainLayer& L = a.L[l];
@@ -237,6 +252,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
       const int nft = (F + T::BF - 1) / T::BF;
       for (int ft = 0; ft < nft; ++ft) {
         const int f0 = ft * T::BF;
+        // staging / fragment geometry, re-derived per tile from an opaque copy of the lane id: a dozen VALU instructions, and
+        // the registers are free during the epilogue instead of being carried through the whole kernel
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int l31 = ln & 31, h = ln >> 5;
+        // piece j of a wave moves rows 8 * (4 j + wave) .. + 7, 16 B per lane
+        int st_row[4], st_k4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          st_row[j] = (j * 4 + wave) * 8 + (ln >> 3);
+          st_k4[j] = 4 * ((ln & 7) ^ ((st_row[j] >> 1) & 7));
+        }
+        int a_rd[T::NFB], a_sw[T::NFB], b_rd[T::NPB], b_sw[T::NPB];
+#pragma unroll
+        for (int fb = 0; fb < T::NFB; ++fb) { const int R = wf + 32 * fb + l31; a_rd[fb] = R * BK; a_sw[fb] = h ^ ((R >> 1) & 7); }
+#pragma unroll
+        for (int pb = 0; pb < T::NPB; ++pb) { const int R = wp + 32 * pb + l31; b_rd[pb] = R * BK; b_sw[pb] = h ^ ((R >> 1) & 7); }
         // ---- staging: direct global -> LDS DMA, XOR-swizzled 16-byte chunks (gemm_glds.h) ----
         auto stage = [&](int k0, float* As, float* Bs, int j) {
           const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr(As) + (unsigned)wave * 1024u);
@@ -258,13 +290,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
             glds16(bb + (size_t)rg * ld + k, __builtin_amdgcn_readfirstlane(lb + (unsigned)jb * 4096u));
           }
         };
-        const unsigned long long tt0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+        const unsigned long long tt0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) stage(0, As0, Bs0, j);
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the asm DMAs are invisible to hipcc's counters
         __syncthreads();
-        const unsigned long long tt1 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+        const unsigned long long tt1 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
 
         f32x16 acc[T::NFB][T::NPB];
 #pragma unroll
@@ -316,14 +348,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
         }
 
         // ---- epilogue (the per-layer kernels' own, on local row coordinates of the tile) ----
-        const unsigned long long tt2 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+        const unsigned long long tt2 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
         const int fw = f0 + wf;
+        const ChainArgs* ep = gp;
+        asm volatile("" : "+s"(ep));          // see the kernel head: epilogue-only fields are loaded here, not at kernel entry
+        const ChainArgs& e = *ep;
         if (L.kind == CK_GN64) {
           chain_gn_silu<64, T::NFB, T::NPB>(acc, L.bias, L.gamma, L.beta, ws + L.out, L.ldo, fw, wp, lane, F);
         } else if (L.kind == CK_GN32) {
           chain_gn_silu<32, T::NFB, T::NPB>(acc, L.bias, L.gamma, L.beta, ws + L.out, L.ldo, fw, wp, lane, F);
         } else if (L.kind == CK_INPUT) {
-          EpiInput::Args ea{L.bias, a.temb, a.ldt, nullptr, nullptr, t, a.cproj + (size_t)p0 * a.ldc, a.ldc, ws + L.out, L.ldo};
+          EpiInput::Args ea{L.bias, e.temb, e.ldt, nullptr, nullptr, t, e.cproj + (size_t)p0 * e.ldc, e.ldc, ws + L.out, L.ldo};
           const EpiInput::Pre<T::NFB> pre = EpiInput::prefetch<T::NFB, true>(ea, fw, lane, F);
           // rows beyond P hold a clamped copy of the last valid row: computed and stored to the private tile like the others (the
           // host pads cproj to whole tiles), never published (the posterior epilogue stores rows < P only)
@@ -331,19 +366,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
         } else {
           EpiPosterior::Args ea{};
           ea.bias = L.bias;
-          ea.xin = a.x + (size_t)p0 * a.D; ea.ldx = a.D;
-          ea.xout = a.x + (size_t)p0 * a.D; ea.ldo = a.D;
-          ea.coef = a.coef; ea.t_dev = nullptr; ea.t_imm = t;
-          ea.z = a.z ? a.z + (size_t)p0 * a.ldzz : nullptr; ea.ldzz = a.ldzz; ea.z_step_stride = a.z_step_stride; ea.t_first = a.z_t_first;
-          ea.seed = a.seed; ea.row_offset = a.row_offset + (uint32_t)p0;
-          ea.mut_mask = a.mut_mask ? a.mut_mask + (size_t)p0 * a.mutation_dim : nullptr; ea.mutation_dim = a.mutation_dim;
+          ea.xin = e.x + (size_t)p0 * e.D; ea.ldx = e.D;
+          ea.xout = e.x + (size_t)p0 * e.D; ea.ldo = e.D;
+          ea.coef = e.coef; ea.t_dev = nullptr; ea.t_imm = t;
+          ea.z = e.z ? e.z + (size_t)p0 * e.ldzz : nullptr; ea.ldzz = e.ldzz; ea.z_step_stride = e.z_step_stride; ea.t_first = e.z_t_first;
+          ea.seed = e.seed; ea.row_offset = e.row_offset + (uint32_t)p0;
+          ea.mut_mask = e.mut_mask ? e.mut_mask + (size_t)p0 * e.mutation_dim : nullptr; ea.mutation_dim = e.mutation_dim;
           const EpiPosterior::Pre<T::NFB> pre = EpiPosterior::prefetch<T::NFB, true>(ea, fw, lane, F);
           EpiPosterior::apply<T::NFB, T::NPB, true, NoSync, false>(acc, ea, pre, fw, wp, lane, F, P);
         }
         // every wave's stores have left before any wave stages the next tile's operands (which may be this output)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (a.stamps) {
+        if constexpr (STAMP) {
           const unsigned long long tt3 = __builtin_amdgcn_s_memtime();
           c_pro += tt1 - tt0; c_k += tt2 - tt1; c_epi += tt3 - tt2;
         }
@@ -357,7 +392,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs a) {
       st_relaxed_agent(a.progress + tile, a.base_done + (unsigned)si + 1u);
     }
   }
-  if (a.stamps && leader) {
+  if (STAMP && a.stamps && leader) {
     unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
     o[0] = c_dep; o[1] = c_pro; o[2] = c_k; o[3] = c_epi; o[4] = __builtin_amdgcn_s_memtime() - c_start; o[5] = c_units;
   }

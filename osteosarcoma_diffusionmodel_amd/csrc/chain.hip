@@ -1,4 +1,5 @@
 // chain.hip -- host side of the persistent reverse-chain kernel (chain.h): eligibility, workspace, launch, status.
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 #include "chain.h"
@@ -30,9 +31,12 @@ static int chain_device_limits(int device, int* max_grid) {
   if (device < 0 || device >= 16) { set_error("device %d out of range", device); return OSD_EINVAL; }
   ChainDev& d = g_chain_dev[device];
   if (!d.ready) {
-    OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
+    OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
+#ifdef OSD_DIAG
+    OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
+#endif
     int occ = 0;
-    OSD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, chain_kernel, NTHREADS, CHAIN_LDS_BYTES));
+    OSD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, chain_kernel<false>, NTHREADS, CHAIN_LDS_BYTES));
     hipDeviceProp_t prop;
     OSD_HIP(hipGetDeviceProperties(&prop, device));
     d.occ = occ < 2 ? occ : 2;              // two 64 KB tiles per CU by design
@@ -94,13 +98,41 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
   int grid = std::min(n_tiles, max_grid);
   if (h->chain_grid > 0) grid = std::min(grid, h->chain_grid);
 
-  // ---- per-slot activation workspace: h0, then (mid, out) of every block ----
+  // ---- per-slot activation workspace.  Buffers: h0, and (mid, out) of every block, each [128][C]; a buffer is live from the
+  // layer that writes it to the last layer that reads it (block outputs of the encoder live on until their decoder block pops
+  // them), and dead buffers are reused first-fit: 0.9 MB per slot instead of 1.9 MB at the BASELINE shape, which is what the
+  // 512 slots keep cycling through L2 / Infinity Cache ----
   ChainArgs ca{};
+  const int nbuf = 1 + 2 * a.n_blocks;                 // 0: h0, 1 + 2b: mid[b], 2 + 2b: out[b]
+  std::vector<int> width(nbuf), def(nbuf), last(nbuf);
+  width[0] = H0; def[0] = 0; last[0] = 1;              // layer index: 0 input_proj, 1 + 2b / 2 + 2b the halves of block b, 1 + 2 n_blocks output_proj
+  for (int b = 0; b < a.n_blocks; ++b) {
+    width[1 + 2 * b] = a.block_out[b]; def[1 + 2 * b] = 1 + 2 * b; last[1 + 2 * b] = 2 + 2 * b;
+    width[2 + 2 * b] = a.block_out[b]; def[2 + 2 * b] = 2 + 2 * b; last[2 + 2 * b] = 3 + 2 * b;     // next block's first half, or output_proj
+    if (a.layers[2 * b].K2 > 0) {
+      const int skip_block = a.n_enc - 1 - (b - a.n_enc - 1);
+      last[2 + 2 * skip_block] = std::max(last[2 + 2 * skip_block], 1 + 2 * b);
+    }
+  }
+  std::vector<int64_t> boff(nbuf, -1);
   int64_t off = 0;
-  auto take = [&](int64_t floats) { const int64_t o = off; off += up64(floats); return (int)o; };
-  const int o_h0 = take((int64_t)BP * H0);
+  {
+    struct Seg { int64_t off, len; int free_from; };    // free_from: first layer index that may overwrite it
+    std::vector<Seg> segs;
+    for (int i = 0; i < nbuf; ++i) {                     // buffers are defined in increasing layer order
+      const int64_t need = up64((int64_t)BP * width[i]);
+      int pick = -1;
+      for (int sgi = 0; sgi < (int)segs.size(); ++sgi)
+        if (segs[sgi].free_from <= def[i] && segs[sgi].len >= need && (pick < 0 || segs[sgi].len < segs[pick].len)) pick = sgi;
+      if (pick < 0) { segs.push_back({off, need, 0}); pick = (int)segs.size() - 1; off += need; }
+      boff[i] = segs[pick].off;
+      // a layer reads its inputs while it writes its output: the segment is reusable by layers AFTER the last reader
+      segs[pick].free_from = last[i] + 1;
+    }
+  }
+  const int o_h0 = (int)boff[0];
   std::vector<int> o_mid(a.n_blocks), o_out(a.n_blocks);
-  for (int b = 0; b < a.n_blocks; ++b) { o_mid[b] = take((int64_t)BP * a.block_out[b]); o_out[b] = take((int64_t)BP * a.block_out[b]); }
+  for (int b = 0; b < a.n_blocks; ++b) { o_mid[b] = (int)boff[1 + 2 * b]; o_out[b] = (int)boff[2 + 2 * b]; }
   ca.ws_stride = off;
   OSD_TRY(ensure_buf(&h->chain_ws, &h->chain_ws_floats, (int64_t)max_grid * off, s));
   ca.ws = h->chain_ws;
@@ -118,7 +150,7 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
   if (x_T) OSD_HIP(launch_copy2d(s, x_T, D, x_out, D, n, D));
   else OSD_HIP(launch_fill_randn(s, x_out, D, n, D, seed, (uint32_t)row_offset, (uint32_t)T, TAG_POSTERIOR));
 
-  // ---- sync words: [status x4 | cu arrivals x2048 | progress x n_tiles], zeroed before every chain ----
+  // ---- sync words: [status, queue, pad x2 | cu arrivals x2048 | progress x n_tiles], zeroed before every chain ----
   const int64_t words = 4 + 2048 + ((n_tiles + 3) / 4) * 4;
   if (h->chain_sync_words < words) {
     if (h->chain_sync) { OSD_HIP(hipStreamSynchronize(s)); OSD_HIP(hipFree(h->chain_sync)); h->chain_sync = nullptr; h->chain_sync_words = 0; }
@@ -127,6 +159,7 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
   }
   OSD_HIP(hipMemsetAsync(h->chain_sync, 0, (size_t)words * 4, s));
   ca.status = h->chain_sync;
+  ca.queue = h->chain_sync + 1;
   ca.cu_arrivals = h->chain_stagger > 0 ? h->chain_sync + 4 : nullptr;
   ca.progress = h->chain_sync + 4 + 2048;
   ca.stagger = h->chain_stagger;
@@ -177,12 +210,37 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
 
   // ---- launches: the whole chain in one, or segments of chain_steps_per_launch steps (progress carries over) ----
   const int seg = h->chain_steps_per_launch > 0 ? h->chain_steps_per_launch : T;
+  const int n_launch = (T + seg - 1) / seg;
+  OSD_HIP(hipStreamSynchronize(s));        // the host copies are about to be rewritten: earlier uploads must have been consumed
+  if (h->chain_args_cap < n_launch) {
+    if (h->chain_args_dev) { OSD_HIP(hipFree(h->chain_args_dev)); h->chain_args_dev = nullptr; }
+    free(h->chain_args_host);
+    h->chain_args_cap = 0;
+    h->chain_args_host = malloc((size_t)n_launch * sizeof(ChainArgs));
+    if (!h->chain_args_host) { set_error("out of host memory"); return OSD_ENOMEM; }
+    if (hipMalloc(&h->chain_args_dev, (size_t)n_launch * sizeof(ChainArgs)) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc failed"); return OSD_ENOMEM; }
+    h->chain_args_cap = n_launch;
+  }
+  ChainArgs* const host_args = static_cast<ChainArgs*>(h->chain_args_host);
+  int launch = 0;
   for (int done = 0; done < T; done += seg) {
     ca.t_first = T - 1 - done;
     ca.n_steps = std::min(seg, T - done);
     ca.base_done = (unsigned)done;
-    if (done > 0 && ca.cu_arrivals) OSD_HIP(hipMemsetAsync(ca.cu_arrivals, 0, 2048 * 4, s));
-    hipLaunchKernelGGL(chain_kernel, dim3(grid), dim3(NTHREADS), CHAIN_LDS_BYTES, s, ca);
+    if (done > 0) {                       // per-launch words: the unit queue and the CU arrival counters (status and progress carry over)
+      OSD_HIP(hipMemsetAsync(ca.queue, 0, 4, s));
+      if (ca.cu_arrivals) OSD_HIP(hipMemsetAsync(ca.cu_arrivals, 0, 2048 * 4, s));
+    }
+    // the argument block of this launch: host copy kept alive in the handle, device copy read by the kernel
+    host_args[launch] = ca;
+    const ChainArgs* dargs = static_cast<const ChainArgs*>(h->chain_args_dev) + launch;
+    OSD_HIP(hipMemcpyAsync(const_cast<ChainArgs*>(dargs), &host_args[launch], sizeof(ChainArgs), hipMemcpyHostToDevice, s));
+    ++launch;
+#ifdef OSD_DIAG
+    if (ca.stamps) hipLaunchKernelGGL(chain_kernel<true>, dim3(grid), dim3(NTHREADS), CHAIN_LDS_BYTES, s, dargs);
+    else
+#endif
+    hipLaunchKernelGGL(chain_kernel<false>, dim3(grid), dim3(NTHREADS), CHAIN_LDS_BYTES, s, dargs);
     OSD_HIP(hipGetLastError());
   }
   h->chain_pending = true;
@@ -194,6 +252,11 @@ void chain_free(osd_handle* h) {
   if (h->chain_ws) e = hipFree(h->chain_ws);
   if (h->chain_cond) e = hipFree(h->chain_cond);
   if (h->chain_sync) e = hipFree(h->chain_sync);
+  if (h->chain_args_dev) e = hipFree(h->chain_args_dev);
+  h->chain_args_dev = nullptr;
+  free(h->chain_args_host);
+  h->chain_args_host = nullptr;
+  h->chain_args_cap = 0;
   (void)e;
   h->chain_ws = h->chain_cond = nullptr;
   h->chain_sync = nullptr;

@@ -122,6 +122,9 @@ struct osd_handle {
   float* chain_ws = nullptr; int64_t chain_ws_floats = 0;
   float* chain_cond = nullptr; int64_t chain_cond_floats = 0;
   unsigned* chain_sync = nullptr; int64_t chain_sync_words = 0;
+  void* chain_args_dev = nullptr;    // device copies of the launches' argument blocks (ChainArgs, chain.h)
+  void* chain_args_host = nullptr;   // host copies of the same (kept alive while their uploads may be pending)
+  int chain_args_cap = 0;
   bool chain_pending = false;        // a chain was launched whose status word has not been read yet
   unsigned long long* chain_stamps = nullptr;   // diagnostic builds (csrc/diag): device buffer of 8 counters per workgroup, else null
   int last_engine = 0;               // engine of the most recent osd_sample_chain (0 per-layer, 1 chain kernel)
