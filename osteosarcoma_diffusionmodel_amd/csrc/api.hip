@@ -363,6 +363,7 @@ int osd_destroy(osd_handle* h) {
   if (h->wgrad_stream) e = hipStreamDestroy(h->wgrad_stream);
   cons_free_plan(&h->cons);
   chain_free(h);
+  wgrad_group_free(h);
   if (h->fork_ev) e = hipEventDestroy(h->fork_ev);
   (void)e;
   delete h;
@@ -405,6 +406,11 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "chain_stagger")) {
     if (value < 0 || value > 100000000) { set_error("chain_stagger must be in [0,1e8] cycles"); return OSD_EINVAL; }
     h->chain_stagger = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "grouped_wgrad")) {           // 1 (default): the weight gradients of a backward pass in two grouped launches
+    if (value < 0 || value > 1) { set_error("grouped_wgrad must be 0 or 1"); return OSD_EINVAL; }
+    h->grouped_wgrad = (int)value;
     return OSD_OK;
   }
   if (!strcmp(name, "train_streams")) {

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
       s_flag = (int)(r & 1u);
     }
     __syncthreads();
-    const int late = s_flag;
+    const int late = __builtin_amdgcn_readfirstlane(s_flag);
     __syncthreads();
     if (late) {
       const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
     // unit was taken earlier by a workgroup that is running, so no wait can depend on a workgroup that is not resident
     if (leader) s_flag = (int)atomicAdd(a.queue, 1u);
     __syncthreads();
-    const long long u = (unsigned)s_flag;
+    const long long u = (unsigned)__builtin_amdgcn_readfirstlane(s_flag);      // wave-uniform by construction: keep it in SGPRs
     __syncthreads();
     if (u >= n_units) break;
     const int tile = (int)(u % a.n_tiles);
@@ -238,9 +238,45 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the barrier must not release before the invalidate is done
     }
     __syncthreads();
-    const int go = s_flag;
+    const int go = __builtin_amdgcn_readfirstlane(s_flag);
     if (!go) return;                      // uniform over the workgroup: every wave leaves
     if constexpr (STAMP) { c_dep += __builtin_amdgcn_s_memtime() - td0; ++c_units; }
+
+    // First K stage of a tile (k in [0, 32)) into LDS buffer 0: the A part (weights: no dependency, so it is issued BEFORE the
+    // previous tile's epilogue and lands under it) and the B part (activations: behind the producing layer's drained stores).
+    auto first_stage = [&](const ChainLayer& Ln, int f0n, bool do_a, bool do_b) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int r0 = wave * 8 + (ln >> 3);                        // piece j moves rows r0 + 32 j
+      const int k4 = 4 * ((ln & 7) ^ ((r0 >> 1) & 7));            // (row >> 1) & 7 does not depend on j
+      const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr(As0) + (unsigned)wave * 1024u);
+      const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(Bs0) + (unsigned)wave * 1024u);
+      if (do_a) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int rg = f0n + r0 + 32 * j;
+          rg = rg < Ln.F ? rg : Ln.F - 1;
+          glds16(Ln.A + (size_t)rg * Ln.lda + k4, __builtin_amdgcn_readfirstlane(la + (unsigned)j * 4096u));
+        }
+      }
+      if (do_b) {
+        const bool from_x = Ln.in0 < 0;
+        const float* bb = from_x ? a.x + (size_t)p0 * a.D : ws + Ln.in0;
+        const int rows = from_x ? P : T::BP;
+        const int kend = Ln.K0 < Ln.K ? Ln.K0 : Ln.K;
+        const int k = k4 < kend - 4 ? k4 : kend - 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int rg = r0 + 32 * j;
+          rg = rg < rows ? rg : rows - 1;
+          glds16(bb + (size_t)rg * Ln.ld0 + k, __builtin_amdgcn_readfirstlane(lb + (unsigned)j * 4096u));
+        }
+      }
+    };
+    unsigned long long tt0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+    first_stage(a.L[0], 0, true, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the asm DMAs are invisible to hipcc's counters
+    __syncthreads();
 
     for (int l = 0; l < a.n_layers; ++l) {
       const ChainLayer& L = a.L[l];
@@ -290,13 +326,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
             glds16(bb + (size_t)rg * ld + k, __builtin_amdgcn_readfirstlane(lb + (unsigned)jb * 4096u));
           }
         };
-        const unsigned long long tt0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) stage(0, As0, Bs0, j);
-
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the asm DMAs are invisible to hipcc's counters
-        __syncthreads();
-        const unsigned long long tt1 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+        const unsigned long long tt1 = STAMP ? __builtin_amdgcn_s_memtime() : 0;     // buffer 0 holds this tile's first K stage
 
         f32x16 acc[T::NFB][T::NPB];
 #pragma unroll
@@ -349,6 +379,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
 
         // ---- epilogue (the per-layer kernels' own, on local row coordinates of the tile) ----
         const unsigned long long tt2 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+        // the next tile of this unit: its weights' first K stage flies under this epilogue (every wave has left the K loop
+        // through its last barrier, so buffer 0 is free)
+        const bool same_layer = ft + 1 < nft;
+        const bool has_next = same_layer || l + 1 < a.n_layers;
+        const int ln_next = same_layer ? l : l + 1;
+        const int f0_next = same_layer ? f0 + T::BF : 0;
+        if (has_next) first_stage(a.L[ln_next], f0_next, true, false);
         const int fw = f0 + wf;
         const ChainArgs* ep = gp;
         asm volatile("" : "+s"(ep));          // see the kernel head: epilogue-only fields are loaded here, not at kernel entry
@@ -375,12 +412,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
           const EpiPosterior::Pre<T::NFB> pre = EpiPosterior::prefetch<T::NFB, true>(ea, fw, lane, F);
           EpiPosterior::apply<T::NFB, T::NPB, true, NoSync, false>(acc, ea, pre, fw, wp, lane, F, P);
         }
-        // every wave's stores have left before any wave stages the next tile's operands (which may be this output)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        unsigned long long tt3 = 0;
+        if (same_layer) {
+          // same input panel, not touched by this epilogue: its first K stage goes out behind the stores, ONE wait covers both
+          first_stage(a.L[ln_next], f0_next, false, true);
+          if constexpr (STAMP) tt3 = __builtin_amdgcn_s_memtime();
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        } else {
+          // layer boundary (or the unit's last tile): every wave's stores have left before any wave stages the next layer's
+          // input, which is this output
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if constexpr (STAMP) tt3 = __builtin_amdgcn_s_memtime();
+          if (has_next) {
+            first_stage(a.L[ln_next], 0, false, true);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+          }
+        }
         if constexpr (STAMP) {
-          const unsigned long long tt3 = __builtin_amdgcn_s_memtime();
           c_pro += tt1 - tt0; c_k += tt2 - tt1; c_epi += tt3 - tt2;
+          tt0 = tt3;
         }
       }
     }

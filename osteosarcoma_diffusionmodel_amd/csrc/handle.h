@@ -114,6 +114,8 @@ struct osd_handle {
   osd::ConsPlan cons;
   double w_pathway = 0.0, w_mutexpr = 0.0;
   float* parts_dev = nullptr;
+  std::vector<void*> wg_plans;       // grouped weight-gradient launches (wgrad_group.hip): one cached work list per flush point
+  int grouped_wgrad = 1;             // osd_set_option("grouped_wgrad", 0|1)
   // persistent reverse-chain kernel (chain.h / chain.hip)
   int sampler = 0;                   // osd_set_option("sampler"): 0 auto, 1 chain kernel whenever the architecture allows, 2 per-layer kernels
   int chain_grid = 0;                // 0 = min(row tiles, resident slots); > 0 caps the workgroup count (tests: force cross-workgroup hand-offs)

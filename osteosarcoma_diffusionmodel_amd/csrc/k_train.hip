@@ -181,9 +181,10 @@ __global__ __launch_bounds__(64 * GN_BWD_WAVES) void k_gn_silu_bwd(GnBwdArgs a) 
   for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
     const int q = i / C, c = i - q * C;
     float v = 0.f;
-    for (int ww = 0; ww < NW; ww += 4)                    // fixed order: deterministic
+    for (int ww = 0; ww < NW; ww += 4)                    // fixed order within the block
       v += (red[(q * NW + ww) * C + c] + red[(q * NW + ww + 1) * C + c]) + (red[(q * NW + ww + 2) * C + c] + red[(q * NW + ww + 3) * C + c]);
-    a.partials[(size_t)blockIdx.x * 3 * C + i] = v;
+    if (a.atomic_cols) atomicAdd((q == 0 ? a.dgamma : q == 1 ? a.dbeta : a.dbias) + c, v);     // targets zeroed by the caller
+    else a.partials[(size_t)blockIdx.x * 3 * C + i] = v;
   }
 }
 
@@ -240,7 +241,7 @@ static hipError_t gn_bwd_go(hipStream_t s, const GnBwdArgs& a) {
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_partial_reduce, (3 * a.C + 63) / 64, 256, 0, s, a.partials, blocks, a.C, a.dgamma, a.dbeta, a.dbias);
+  if (!a.atomic_cols) hipLaunchKernelGGL(k_partial_reduce, (3 * a.C + 63) / 64, 256, 0, s, a.partials, blocks, a.C, a.dgamma, a.dbeta, a.dbias);
   return hipGetLastError();
 }
 hipError_t launch_gn_silu_bwd(hipStream_t s, int gw, const GnBwdArgs& a) {

@@ -21,6 +21,8 @@ struct GnBwdArgs {
   float* gz;             // dL/dz                          [rows][C]
   float* dgamma; float* dbeta; float* dbias;   // [C], overwritten
   float* partials;                             // workspace [GN_BWD_MAX_BLOCKS][3][C]
+  int atomic_cols;                             // 1: per-block column sums go straight into (pre-zeroed) dgamma / dbeta / dbias with float
+                                               // atomics (one launch less per layer); 0: partial rows + k_partial_reduce, deterministic
   int64_t rows; int C;
   int drop_mode; const float* mask; float keep_scale; float p_drop;
   uint64_t seed; uint32_t row_offset; uint32_t step; uint32_t tag;
@@ -29,6 +31,11 @@ constexpr int GN_BWD_MAX_BLOCKS = 256;
 hipError_t launch_gn_silu_bwd(hipStream_t s, int gw, const GnBwdArgs& a);
 hipError_t launch_slab_reduce(hipStream_t s, const float* slabs, int ns, int rows, int cols, int64_t stride, float* out, int ldo);
 hipError_t launch_small_wgrad(hipStream_t s, const float* x, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw);
+
+// ---- grouped weight gradients (wgrad_group.h / wgrad_group.hip) -----------------------------------------------
+// dw[nout][kin] (leading dimension lddw) = sum over rows of gz[row][nout] * x[row][kin]
+struct WgPending { const float* x; int ldx; int kin; const float* gz; int ldg; int nout; int64_t rows; float* dw; int lddw; };
+bool wgrad_group_ok(const WgPending& w);
 
 struct AdamArgs {
   float decay;          // 1 - lr*wd

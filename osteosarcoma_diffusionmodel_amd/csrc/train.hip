@@ -64,7 +64,12 @@ static int64_t carve_train(const Arch& a, float* base, int64_t n, const ConsPlan
 // dW[n_out][k_in] = sum_m gz[m][n_out] * x[m][k_in].  The reduction runs over the batch, the output is only
 // n_out x k_in: split the batch over blockIdx.y so that ~1024 workgroups exist, each writing its partial
 // tile to a slab, then sum the slabs in a fixed order (deterministic; no float atomics).
-static hipError_t wgrad(hipStream_t s, const TrainWs& w, const float* x, int ldx, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, int lddw) {
+static hipError_t wgrad(hipStream_t s, const TrainWs& w, const float* x, int ldx, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, int lddw,
+                        std::vector<WgPending>* group = nullptr) {
+  if (group) {
+    const WgPending wp{x, ldx, kin, gz, ldg, nout, rows, dw, lddw};
+    if (kin >= 16 && wgrad_group_ok(wp)) { group->push_back(wp); return hipSuccess; }     // launched by the next flush
+  }
   if (kin <= 8 && nout * kin <= 1024 && lddw == kin) return launch_small_wgrad(s, x, kin, gz, ldg, nout, rows, dw);
   GemmArgs g{};
   g.A = x; g.lda = ldx; g.B0 = gz; g.ldb0 = ldg; g.K0 = (int)rows; g.F = kin; g.P = nout; g.K = (int)rows;
@@ -127,6 +132,9 @@ static void add_backward_zeros(const Arch& a, const TrainWs& w, float* const* gr
   add(w.g_temb, (int64_t)a.T * a.H0);
   const int small[] = {pm.ce0_b, pm.ce2_b, pm.in_b, pm.cp_b, pm.tp_b, pm.out_b};
   for (int i : small) add(grads[i], pm.numel[i]);
+  for (const LayerDesc& l : a.layers) {          // GroupNorm backward adds its per-block column sums atomically
+    add(grads[l.b], pm.numel[l.b]); add(grads[l.gamma], pm.numel[l.gamma]); add(grads[l.beta], pm.numel[l.beta]);
+  }
 }
 
 
@@ -173,15 +181,29 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     OSD_HIP(hipStreamWaitEvent(s2, e, 0));
     return OSD_OK;
   };
-  int ev = 0;
-  auto record = [&]() -> int {        // bucket complete: its last writer is on the side stream
-    if (events) OSD_HIP(hipEventRecord((hipEvent_t)events[ev], s2));
-    ++ev;
+  // Weight gradients are leaves: they are collected and launched as ONE grouped GEMM per flush point (after the decoder +
+  // bottleneck half of the backward pass, and at its end) instead of ~17 launches of a few tiles each.  A gradient bucket is
+  // final once the flush that carries its weight gradients has been enqueued, so bucket events are recorded there.
+  std::vector<WgPending> pend;
+  std::vector<WgPending>* grp = h->grouped_wgrad ? &pend : nullptr;
+  int ev = 0, ev_closed = 0, n_flush = 0;
+  auto record = [&]() -> int {        // bucket complete up to the pending weight gradients
+    ++ev_closed;
+    if (!grp) { if (events) OSD_HIP(hipEventRecord((hipEvent_t)events[ev], s2)); ++ev; }
+    return OSD_OK;
+  };
+  auto flush = [&]() -> int {
+    if (!grp) return OSD_OK;
+    OSD_TRY(fork());                  // the side stream sees every gz produced so far
+    OSD_TRY(wgrad_group_flush(h, s2, n_flush++, pend, W.slabs, W.slab_floats));
+    pend.clear();
+    for (; ev < ev_closed; ++ev)
+      if (events) OSD_HIP(hipEventRecord((hipEvent_t)events[ev], s2));
     return OSD_OK;
   };
   // output_proj
   OSD_TRY(fork());
-  OSD_HIP(wgrad(s2, W, W.f.out[last], Hl, Hl, d_out, D, D, n, grads[pm.out_w], Hl));
+  OSD_HIP(wgrad(s2, W, W.f.out[last], Hl, Hl, d_out, D, D, n, grads[pm.out_w], Hl, grp));
   OSD_HIP(launch_colsum(s2, d_out, D, n, D, grads[pm.out_b]));
   OSD_TRY(record());
   OSD_HIP(dgrad(s, h->params[pm.out_w], Hl, Hl, d_out, D, D, n, W.g_out[last], Hl, false));
@@ -195,16 +217,16 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     GnBwdArgs ga{};
     ga.g = W.g_out[b]; ga.z = W.f.z2[b]; ga.stats = W.f.st2[b]; ga.gamma = h->params[l2.gamma]; ga.beta = h->params[l2.beta];
     ga.gz = W.g_z2[b]; ga.dgamma = grads[l2.gamma]; ga.dbeta = grads[l2.beta]; ga.dbias = grads[l2.b];
-    ga.rows = n; ga.C = C; ga.drop_mode = 0; ga.partials = W.partials;
+    ga.rows = n; ga.C = C; ga.drop_mode = 0; ga.partials = W.partials; ga.atomic_cols = 1;
     OSD_HIP(launch_gn_silu_bwd(s, l2.gw, ga));
     OSD_TRY(fork());
-    OSD_HIP(wgrad(s2, W, W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C));
+    OSD_HIP(wgrad(s2, W, W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C, grp));
     OSD_HIP(dgrad(s, h->params[l2.w], C, C, W.g_z2[b], C, C, n, W.g_mid[b], C, false));
     // first half (dropout sits behind it)
     GnBwdArgs gb{};
     gb.g = W.g_mid[b]; gb.z = W.f.z1[b]; gb.stats = W.f.st1[b]; gb.gamma = h->params[l1.gamma]; gb.beta = h->params[l1.beta];
     gb.gz = W.g_z1[b]; gb.dgamma = grads[l1.gamma]; gb.dbeta = grads[l1.beta]; gb.dbias = grads[l1.b];
-    gb.rows = n; gb.C = C; gb.partials = W.partials;
+    gb.rows = n; gb.C = C; gb.partials = W.partials; gb.atomic_cols = 1;
     gb.drop_mode = drop ? (masks ? 1 : 2) : 0;
     gb.mask = (drop && masks) ? masks[b] : nullptr; gb.keep_scale = keep_scale; gb.p_drop = h->cfg.dropout_p;
     gb.seed = seed; gb.row_offset = roff; gb.step = 0; gb.tag = TAG_DROPOUT + (uint32_t)b;
@@ -212,13 +234,14 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     OSD_TRY(fork());
     const int Kt = l1.K1 + l1.K2;
     const float* xin = (b == 0) ? W.f.h0 : W.f.out[b - 1];
-    OSD_HIP(wgrad(s2, W, xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt));
+    OSD_HIP(wgrad(s2, W, xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt, grp));
     int skip_block = -1;
     if (l1.K2 > 0) {
       skip_block = a.n_enc - 1 - (b - a.n_enc - 1);
-      OSD_HIP(wgrad(s2, W, W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt));
+      OSD_HIP(wgrad(s2, W, W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt, grp));
     }
     OSD_TRY(record());
+    if (b == a.n_enc) OSD_TRY(flush());          // decoder blocks + bottleneck done: first half of the weight gradients
     // dgrad into the producer of the main input; encoder outputs already hold their skip gradient
     float* gdst = (b == 0) ? W.g_h0 : W.g_out[b - 1];
     const bool acc = (b >= 1) && (b - 1 < a.n_enc);
@@ -228,8 +251,8 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   // input_proj, time_proj, cond_proj, ConditionalEmbedding  (h0 = x W^T + b + t_emb[t] + c_proj)
   OSD_TRY(fork());
   if (dx_t) OSD_HIP(dgrad(s, h->params[pm.in_w], D, D, W.g_h0, a.H0, a.H0, n, dx_t, D, false));
-  OSD_HIP(wgrad(s2, W, x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D));
-  OSD_HIP(wgrad(s2, W, W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64));
+  OSD_HIP(wgrad(s2, W, x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D, grp));
+  OSD_HIP(wgrad(s2, W, W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64, grp));
   OSD_HIP(launch_colsum(s2, W.g_h0, a.H0, n, a.H0, grads[pm.in_b]));
   OSD_HIP(hipMemcpyAsync(grads[pm.cp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s2));
   OSD_HIP(hipMemcpyAsync(grads[pm.tp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s2));
@@ -237,7 +260,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   OSD_HIP(dgrad(s, h->params[pm.cp_w], 64, 64, W.g_h0, a.H0, a.H0, n, W.g_ce2, 64, false));
   OSD_TRY(fork());
   OSD_HIP(wgrad(s2, W, h->d_time_emb, a.time_dim, a.time_dim, W.g_temb, a.H0, a.H0, a.T, grads[pm.tp_w], a.time_dim));
-  OSD_HIP(wgrad(s2, W, W.f.ce1, 64, 64, W.g_ce2, 64, 64, n, grads[pm.ce2_w], 64));
+  OSD_HIP(wgrad(s2, W, W.f.ce1, 64, 64, W.g_ce2, 64, 64, n, grads[pm.ce2_w], 64, grp));
   OSD_HIP(launch_colsum(s2, W.g_ce2, 64, n, 64, grads[pm.ce2_b]));
   OSD_HIP(dgrad(s, h->params[pm.ce2_w], 64, 64, W.g_ce2, 64, 64, n, W.g_ce1, 64, false));
   OSD_HIP(launch_silu_bwd(s, W.u0, W.g_ce1, W.g_u, n * 64));
@@ -245,6 +268,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   OSD_HIP(wgrad(s2, W, cond, a.cond_dim, a.cond_dim, W.g_u, 64, 64, n, grads[pm.ce0_w], a.cond_dim));
   OSD_HIP(launch_colsum(s2, W.g_u, 64, n, 64, grads[pm.ce0_b]));
   OSD_TRY(record());
+  OSD_TRY(flush());
   if (s2 != s) {                      // join: the caller's stream owns every result again
     hipEvent_t e;
     OSD_TRY(next_event(&e));

@@ -1,0 +1,111 @@
+// wgrad_group.hip -- host side of the grouped weight-gradient launch (wgrad_group.h): eligibility, the work-item list
+// (tensor x 128 x 128 tile x row range), slabs for split row ranges, upload (only when the list changed), launch.
+#include <string.h>
+#include <algorithm>
+#include "wgrad_group.h"
+#include "handle.h"
+#include "kernels_train.h"
+
+namespace osd {
+
+static bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+bool wgrad_group_ok(const WgPending& w) {
+  return w.rows >= WG_BK && w.rows % WG_BK == 0 && w.kin >= 4 && w.kin % 4 == 0 && w.nout >= 4 && w.nout % 4 == 0 && w.ldx % 4 == 0 &&
+         w.ldg % 4 == 0 && w.lddw % 4 == 0 && al16p(w.x) && al16p(w.gz) && al16p(w.dw);
+}
+
+struct WgPlanDev {
+  std::vector<WgItem> items;
+  std::vector<WgReduce> reds;
+  WgItem* d_items = nullptr; size_t cap_items = 0;
+  WgReduce* d_reds = nullptr; size_t cap_reds = 0;
+};
+
+static bool g_wg_attr[16] = {};
+
+void wgrad_group_free(osd_handle* h) {
+  for (void* p : h->wg_plans) {
+    WgPlanDev* pl = static_cast<WgPlanDev*>(p);
+    hipError_t e = hipSuccess;
+    if (pl->d_items) e = hipFree(pl->d_items);
+    if (pl->d_reds) e = hipFree(pl->d_reds);
+    (void)e;
+    delete pl;
+  }
+  h->wg_plans.clear();
+}
+
+template <class V, class D>
+static int upload(hipStream_t s, const V& fresh, V& kept, D** dev, size_t* cap) {
+  typedef typename V::value_type E;
+  const bool same = fresh.size() == kept.size() && (fresh.empty() || memcmp(fresh.data(), kept.data(), fresh.size() * sizeof(E)) == 0) && *dev;
+  if (same) return OSD_OK;
+  OSD_HIP(hipStreamSynchronize(s));            // rare (first step, or the batch / tensors changed): the old list may still be in use
+  if (*cap < fresh.size()) {
+    if (*dev) OSD_HIP(hipFree(*dev));
+    *dev = nullptr; *cap = 0;
+    const size_t want = std::max<size_t>(fresh.size(), 64);
+    if (hipMalloc((void**)dev, want * sizeof(E)) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc failed"); return OSD_ENOMEM; }
+    *cap = want;
+  }
+  kept = fresh;
+  if (!kept.empty()) OSD_HIP(hipMemcpyAsync(*dev, kept.data(), kept.size() * sizeof(E), hipMemcpyHostToDevice, s));
+  return OSD_OK;
+}
+
+// Launch every pending weight gradient as one grouped GEMM (+ one slab reduction) on stream s.
+int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::vector<WgPending>& pend, float* slabs, int64_t slab_floats) {
+  if (pend.empty()) return OSD_OK;
+  while ((int)h->wg_plans.size() <= plan_index) h->wg_plans.push_back(new WgPlanDev());
+  WgPlanDev* pl = static_cast<WgPlanDev*>(h->wg_plans[plan_index]);
+  const int dev = h->cfg.device;
+  if (dev >= 0 && dev < 16 && !g_wg_attr[dev]) {
+    OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES));
+    g_wg_attr[dev] = true;
+  }
+  // row range per item: about two workgroups per CU over the whole list, never fewer than 8 K steps per item
+  long total = 0;
+  for (const WgPending& w : pend) total += (long)((w.kin + 127) / 128) * ((w.nout + 127) / 128) * (w.rows / WG_BK);
+  static const int target_items = [] { const char* e = getenv("OSD_WGRAD_ITEMS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+  const long per_item = std::max<long>(8, (total + target_items - 1) / target_items);
+  std::vector<WgItem> items;
+  std::vector<WgReduce> reds;
+  int64_t slab_off = 0;
+  for (const WgPending& w : pend) {
+    const int ksteps = (int)(w.rows / WG_BK);
+    int n_slices = (int)std::max<long>(1, (ksteps + per_item / 2) / per_item);
+    const int64_t numel = (int64_t)w.nout * w.kin;
+    while (n_slices > 1 && slab_off + (int64_t)n_slices * numel > slab_floats) --n_slices;
+    const int per = (ksteps + n_slices - 1) / n_slices;
+    n_slices = (ksteps + per - 1) / per;
+    float* slab = slabs + slab_off;
+    if (n_slices > 1) {
+      reds.push_back({w.dw, w.lddw, slab, numel, w.nout, w.kin, n_slices});
+      slab_off += (int64_t)n_slices * ((numel + 3) / 4 * 4);
+    }
+    for (int p0 = 0; p0 < w.nout; p0 += 128)
+      for (int f0 = 0; f0 < w.kin; f0 += 128)
+        for (int sl = 0; sl < n_slices; ++sl) {
+          WgItem it{};
+          it.A = w.x; it.lda = w.ldx; it.B = w.gz; it.ldb = w.ldg; it.F = w.kin; it.P = w.nout; it.f0 = f0; it.p0 = p0;
+          it.k0 = sl * per * WG_BK; it.k1 = std::min<int>((sl + 1) * per, ksteps) * WG_BK;
+          if (n_slices > 1) { it.out = slab + (int64_t)sl * numel; it.ldo = w.kin; }
+          else { it.out = w.dw; it.ldo = w.lddw; }
+          items.push_back(it);
+        }
+  }
+  // longest items first: the tail of the launch is then made of short ones
+  std::stable_sort(items.begin(), items.end(), [](const WgItem& a, const WgItem& b) { return (a.k1 - a.k0) > (b.k1 - b.k0); });
+  OSD_TRY(upload(s, items, pl->items, &pl->d_items, &pl->cap_items));
+  OSD_TRY(upload(s, reds, pl->reds, &pl->d_reds, &pl->cap_reds));
+  hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)pl->items.size()), dim3(NTHREADS), WG_LDS_BYTES, s, pl->d_items);
+  OSD_HIP(hipGetLastError());
+  if (!pl->reds.empty()) {
+    hipLaunchKernelGGL(wgrad_group_reduce, dim3(64, (unsigned)pl->reds.size()), dim3(256), 0, s, pl->d_reds);
+    OSD_HIP(hipGetLastError());
+  }
+  return OSD_OK;
+}
+
+}  // namespace osd
