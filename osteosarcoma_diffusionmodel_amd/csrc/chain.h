@@ -76,15 +76,22 @@ __device__ __forceinline__ void st_relaxed_agent(unsigned* p, unsigned v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One lane waits until *word >= want (or the chain failed elsewhere, or the budget ran out).  Returns false on failure.
-__device__ __forceinline__ bool chain_wait(const unsigned* word, unsigned want, unsigned* status, unsigned long long budget) {
-  if (ld_relaxed_agent(word) >= want) return true;
+// Wave 0 waits until *word >= want (or the chain failed elsewhere, or the budget ran out); false on failure.  Executed by
+// the WHOLE wave with wave-uniform control flow: every lane loads the same word and the decision is taken on lane 0's copy
+// (readfirstlane), so no branch here depends on a lane id.  A lane-divergent `if (tid == 0) { poll ... }` next to workgroup
+// barriers lets hipcc lay the two lane groups of wave 0 on different paths to the same s_barrier (seen: the non-leader
+// lanes' path ran the barrier on its own and the workgroup deadlocked).
+__device__ __forceinline__ bool chain_wait(const unsigned* word, unsigned want, unsigned* status, unsigned long long budget, int lane) {
+  if ((unsigned)__builtin_amdgcn_readfirstlane((int)ld_relaxed_agent(word)) >= want) return true;
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (;;) {
     __builtin_amdgcn_s_sleep(32);
-    if (ld_relaxed_agent(word) >= want) return true;
-    if (ld_relaxed_agent(status) != CHAIN_OK) return false;
-    if (__builtin_amdgcn_s_memrealtime() - t0 > budget) { st_relaxed_agent(status, CHAIN_TIMEOUT); return false; }
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)ld_relaxed_agent(word)) >= want) return true;
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)ld_relaxed_agent(status)) != CHAIN_OK) return false;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > budget) {
+      if (lane == 0) st_relaxed_agent(status, CHAIN_TIMEOUT);
+      return false;
+    }
   }
 }
 
@@ -160,6 +167,12 @@ __device__ __forceinline__ void chain_gn_silu(f32x16 (&acc)[NFB][NPB], const flo
   }
 }
 
+#ifndef CHAIN_WIDE_X
+#define CHAIN_WIDE_X false
+#endif
+#ifndef CHAIN_EPI_PRIO
+#define CHAIN_EPI_PRIO 0
+#endif
 typedef Tile<128, 128, 64, 64> ChainTile;
 constexpr int CHAIN_LDS_BYTES = GldsTile<ChainTile>::LDS_BYTES + 16;
 
@@ -187,18 +200,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wf = (wave / T::NWP) * T::WF;
   const int wp = (wave % T::NWP) * T::WP;
-  const bool leader = tid == 0;
 
   float* const ws = a.ws + (long long)blockIdx.x * a.ws_stride;
 
   // ---- stagger: the second workgroup to arrive on a CU starts `stagger` cycles late, once ----
   if (a.cu_arrivals && a.stagger > 0) {
-    if (leader) {
+    if (wave == 0) {                      // wave-uniform branch; only the atomic itself is under a lane mask
       const unsigned hw = __builtin_amdgcn_s_getreg(0xF804);      // HW_REG_HW_ID: cu [11:8], sh [12], se [15:13]
       const unsigned xcc = __builtin_amdgcn_s_getreg(0xF814) & 7; // HW_REG_XCC_ID
       const unsigned key = (xcc << 8) | ((hw >> 8) & 0xFF);
-      const unsigned r = atomicAdd(a.cu_arrivals + key, 1u);
-      s_flag = (int)(r & 1u);
+      unsigned r = 0;
+      if (lane == 0) r = atomicAdd(a.cu_arrivals + key, 1u);
+      s_flag = __builtin_amdgcn_readfirstlane((int)(r & 1u));     // every lane stores lane 0's value
     }
     __syncthreads();
     const int late = __builtin_amdgcn_readfirstlane(s_flag);
@@ -212,14 +225,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
   unsigned long long c_dep = 0, c_pro = 0, c_k = 0, c_epi = 0, c_units = 0;
   const unsigned long long c_start = STAMP ? __builtin_amdgcn_s_memtime() : 0;
   const long long n_units = (long long)a.n_tiles * a.n_steps;
+  int c_iter = 0;
+  (void)c_iter;
   for (;;) {
     const unsigned long long td0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
     // next unit, in global order: whoever is free takes it (a slow workgroup simply takes fewer), and every dependency of a
     // unit was taken earlier by a workgroup that is running, so no wait can depend on a workgroup that is not resident
-    if (leader) s_flag = (int)atomicAdd(a.queue, 1u);
+#ifdef CHAIN_STATIC_UNITS
+    static_assert(true, "");
+    const long long u = (long long)blockIdx.x + (long long)c_iter * gridDim.x;
+    ++c_iter;
+#else
+    if (wave == 0) {
+      unsigned nu = 0;
+      if (lane == 0) nu = atomicAdd(a.queue, 1u);
+      s_flag = __builtin_amdgcn_readfirstlane((int)nu);
+    }
     __syncthreads();
     const long long u = (unsigned)__builtin_amdgcn_readfirstlane(s_flag);      // wave-uniform by construction: keep it in SGPRs
     __syncthreads();
+#endif
     if (u >= n_units) break;
     const int tile = (int)(u % a.n_tiles);
     const int si = (int)(u / a.n_tiles);
@@ -228,10 +253,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
     const int P = (a.n - p0 < T::BP) ? a.n - p0 : T::BP;      // valid rows of this tile
 
     // ---- dependency: x_t of this tile (written by the unit n_tiles earlier, another workgroup) ----
-    if (leader) {
-      bool ok = ld_relaxed_agent(a.status) == CHAIN_OK;
+    if (wave == 0) {
+      bool ok = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_relaxed_agent(a.status)) == CHAIN_OK;
       if (ok && si > 0) {
-        ok = chain_wait(a.progress + tile, a.base_done + (unsigned)si, a.status, a.spin_budget);
+        ok = chain_wait(a.progress + tile, a.base_done + (unsigned)si, a.status, a.spin_budget, lane);
         if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE buffer_inv sc1 after the match
       }
       s_flag = ok ? 1 : 0;
@@ -244,7 +269,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
 
     // First K stage of a tile (k in [0, 32)) into LDS buffer 0: the A part (weights: no dependency, so it is issued BEFORE the
     // previous tile's epilogue and lands under it) and the B part (activations: behind the producing layer's drained stores).
-    auto first_stage = [&](const ChainLayer& Ln, int f0n, bool do_a, bool do_b) {
+    auto first_stage = [&](const ChainLayer& Lr, int f0n, bool do_a, bool do_b) {
+      struct { const float* A; int lda, F, in0, ld0, K0, K; } Ln{Lr.A, Lr.lda, Lr.F, Lr.in0, Lr.ld0, Lr.K0, Lr.K};   // values, not re-loads
+      const float* const xrows = a.x + (size_t)p0 * a.D;
       int ln = lane;
       asm volatile("" : "+v"(ln));
       const int r0 = wave * 8 + (ln >> 3);                        // piece j moves rows r0 + 32 j
@@ -261,7 +288,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
       }
       if (do_b) {
         const bool from_x = Ln.in0 < 0;
-        const float* bb = from_x ? a.x + (size_t)p0 * a.D : ws + Ln.in0;
+        const float* bb = from_x ? xrows : ws + Ln.in0;
         const int rows = from_x ? P : T::BP;
         const int kend = Ln.K0 < Ln.K ? Ln.K0 : Ln.K;
         const int k = k4 < kend - 4 ? k4 : kend - 4;
@@ -280,6 +307,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
 
     for (int l = 0; l < a.n_layers; ++l) {
       const ChainLayer& L = a.L[l];
+      // the K loop's operands as plain values: the DMA asm statements clobber "memory", and a field read through the argument
+      // block after one of them would be re-loaded from device memory every time (measured: the K loop ran at half speed)
+      const float* const LA = L.A;
+      const int Llda = L.lda, LK0 = L.K0, Lld0 = L.ld0, Lld1 = L.ld1;
       const int F = L.F, K = L.K;
       const float* B0 = (L.in0 < 0) ? a.x + (size_t)p0 * a.D : ws + L.in0;
       const float* B1 = ws + L.in1;
@@ -312,14 +343,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
           if (j < 4) {
             int rg = f0 + st_row[j];
             rg = rg < F ? rg : F - 1;
-            glds16(L.A + (size_t)rg * L.lda + k0 + st_k4[j], __builtin_amdgcn_readfirstlane(la + (unsigned)j * 4096u));
+            glds16(LA + (size_t)rg * Llda + k0 + st_k4[j], __builtin_amdgcn_readfirstlane(la + (unsigned)j * 4096u));
           } else {
             const int jb = j - 4;
-            const bool first = k0 < L.K0;            // uniform: K0 is a multiple of BK (or >= K)
+            const bool first = k0 < LK0;            // uniform: K0 is a multiple of BK (or >= K)
             const float* bb = first ? B0 : B1;
-            const int ld = first ? L.ld0 : L.ld1;
-            const int kend = first ? (L.K0 < K ? L.K0 : K) : K - L.K0;
-            int k = (first ? k0 : k0 - L.K0) + st_k4[jb];
+            const int ld = first ? Lld0 : Lld1;
+            const int kend = first ? (LK0 < K ? LK0 : K) : K - LK0;
+            int k = (first ? k0 : k0 - LK0) + st_k4[jb];
             k = k < kend - 4 ? k : kend - 4;
             int rg = st_row[jb];
             rg = rg < rowsB ? rg : rowsB - 1;
@@ -387,6 +418,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
         const int f0_next = same_layer ? f0 + T::BF : 0;
         if (has_next) first_stage(a.L[ln_next], f0_next, true, false);
         const int fw = f0 + wf;
+        if (CHAIN_EPI_PRIO) __builtin_amdgcn_s_setprio(CHAIN_EPI_PRIO);
         const ChainArgs* ep = gp;
         asm volatile("" : "+s"(ep));          // see the kernel head: epilogue-only fields are loaded here, not at kernel entry
         const ChainArgs& e = *ep;
@@ -410,8 +442,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
           ea.seed = e.seed; ea.row_offset = e.row_offset + (uint32_t)p0;
           ea.mut_mask = e.mut_mask ? e.mut_mask + (size_t)p0 * e.mutation_dim : nullptr; ea.mutation_dim = e.mutation_dim;
           const EpiPosterior::Pre<T::NFB> pre = EpiPosterior::prefetch<T::NFB, true>(ea, fw, lane, F);
-          EpiPosterior::apply<T::NFB, T::NPB, true, NoSync, false>(acc, ea, pre, fw, wp, lane, F, P);
+          EpiPosterior::apply<T::NFB, T::NPB, true, NoSync, CHAIN_WIDE_X>(acc, ea, pre, fw, wp, lane, F, P);
         }
+        if (CHAIN_EPI_PRIO) __builtin_amdgcn_s_setprio(0);
         unsigned long long tt3 = 0;
         if (same_layer) {
           // same input panel, not touched by this epilogue: its first K stage goes out behind the stores, ONE wait covers both
@@ -439,13 +472,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
     }
 
     // ---- publish x_{t-1} of this tile: all waves drained (above), then ONE agent-scope release and the progress word ----
-    if (leader) {
+    if (wave == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // hipcc may drop the fence's own wait (Guideline 16, pitfall 12)
-      st_relaxed_agent(a.progress + tile, a.base_done + (unsigned)si + 1u);
+      if (lane == 0) st_relaxed_agent(a.progress + tile, a.base_done + (unsigned)si + 1u);
     }
   }
-  if (STAMP && a.stamps && leader) {
+  if (STAMP && a.stamps && tid == 0) {
     unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
     o[0] = c_dep; o[1] = c_pro; o[2] = c_k; o[3] = c_epi; o[4] = __builtin_amdgcn_s_memtime() - c_start; o[5] = c_units;
   }

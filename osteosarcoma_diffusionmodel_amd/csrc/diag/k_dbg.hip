@@ -271,3 +271,16 @@ extern "C" int osd_dbg_chain_stamps(osd_handle* h, unsigned long long* buf) {
   h->chain_stamps = buf;
   return OSD_OK;
 }
+
+// diagnostic: read the chain kernel's sync words ([status, queue, -, -], then progress[0..]) while a launch may still be
+// running (own stream, so it does not wait for the handle's stream)
+extern "C" int osd_dbg_chain_peek(osd_handle* h, unsigned* out8) {
+  if (!h || !h->chain_sync) return OSD_ESTATE;
+  hipStream_t ps;
+  OSD_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+  OSD_HIP(hipMemcpyAsync(out8, h->chain_sync, 16, hipMemcpyDeviceToHost, ps));
+  OSD_HIP(hipMemcpyAsync(out8 + 4, h->chain_sync + 4 + 2048, 16, hipMemcpyDeviceToHost, ps));
+  OSD_HIP(hipStreamSynchronize(ps));
+  OSD_HIP(hipStreamDestroy(ps));
+  return OSD_OK;
+}
