@@ -326,6 +326,7 @@ int osd_create(const osd_config* cfg, osd_handle** out) {
   if (!h) { set_error("out of host memory"); return OSD_ENOMEM; }
   h->cfg = *cfg;
   h->arch = a;
+  if (const char* e = getenv("OSD_GROUPED_WGRAD")) h->grouped_wgrad = atoi(e) != 0;      // A/B knob, see osd_set_option
   const int rc = create_device_state(h);
   if (rc != OSD_OK) {                 // nothing of a half-built handle survives (osd_destroy frees what was allocated)
     osd_destroy(h);

@@ -33,7 +33,8 @@ int chain_check_status(osd_handle* h);
 void chain_free(osd_handle* h);
 // wgrad_group.hip
 struct WgPending;
-int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::vector<WgPending>& pend, float* slabs, int64_t slab_floats);
+int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::vector<WgPending>& pend, float* slabs, int64_t slab_floats,
+                      int max_grid);
 void wgrad_group_free(osd_handle* h);
 int check_row_offset(int64_t row_offset, int64_t n);
 int sanitize_t(osd_handle* h, hipStream_t s, const int32_t* t_index, int64_t n, const int** out);

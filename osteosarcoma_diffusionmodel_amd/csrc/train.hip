@@ -64,12 +64,7 @@ static int64_t carve_train(const Arch& a, float* base, int64_t n, const ConsPlan
 // dW[n_out][k_in] = sum_m gz[m][n_out] * x[m][k_in].  The reduction runs over the batch, the output is only
 // n_out x k_in: split the batch over blockIdx.y so that ~1024 workgroups exist, each writing its partial
 // tile to a slab, then sum the slabs in a fixed order (deterministic; no float atomics).
-static hipError_t wgrad(hipStream_t s, const TrainWs& w, const float* x, int ldx, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, int lddw,
-                        std::vector<WgPending>* group = nullptr) {
-  if (group) {
-    const WgPending wp{x, ldx, kin, gz, ldg, nout, rows, dw, lddw};
-    if (kin >= 16 && wgrad_group_ok(wp)) { group->push_back(wp); return hipSuccess; }     // launched by the next flush
-  }
+static hipError_t wgrad(hipStream_t s, const TrainWs& w, const float* x, int ldx, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, int lddw) {
   if (kin <= 8 && nout * kin <= 1024 && lddw == kin) return launch_small_wgrad(s, x, kin, gz, ldg, nout, rows, dw);
   GemmArgs g{};
   g.A = x; g.lda = ldx; g.B0 = gz; g.ldb0 = ldg; g.K0 = (int)rows; g.F = kin; g.P = nout; g.K = (int)rows;
@@ -192,18 +187,30 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     if (!grp) { if (events) OSD_HIP(hipEventRecord((hipEvent_t)events[ev], s2)); ++ev; }
     return OSD_OK;
   };
-  auto flush = [&]() -> int {
+  // a weight gradient: deferred to the next grouped launch when eligible, else launched now on the side stream (which then
+  // has to see what the main stream produced: each fork costs the main stream a few microseconds, so only then)
+  auto wg = [&](const float* x, int ldx, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, int lddw) -> int {
+    const WgPending wp{x, ldx, kin, gz, ldg, nout, rows, dw, lddw};
+    if (grp && kin >= 16 && wgrad_group_ok(wp)) { pend.push_back(wp); return OSD_OK; }
+    OSD_TRY(fork());
+    OSD_HIP(wgrad(s2, W, x, ldx, kin, gz, ldg, nout, rows, dw, lddw));
+    return OSD_OK;
+  };
+  auto flush = [&](bool leave_room) -> int {
     if (!grp) return OSD_OK;
     OSD_TRY(fork());                  // the side stream sees every gz produced so far
-    OSD_TRY(wgrad_group_flush(h, s2, n_flush++, pend, W.slabs, W.slab_floats));
+    // mid-pass flush: one workgroup per CU walks the list, the other slot of every CU stays with the dgrad chain of the
+    // main stream (a full-width launch starved it: a 16 us dgrad took 104 us); the final flush has the GPU to itself
+    const int cap = (leave_room && s2 != s) ? 256 : 0;
+    OSD_TRY(wgrad_group_flush(h, s2, n_flush++, pend, W.slabs, W.slab_floats, cap));
     pend.clear();
     for (; ev < ev_closed; ++ev)
       if (events) OSD_HIP(hipEventRecord((hipEvent_t)events[ev], s2));
     return OSD_OK;
   };
   // output_proj
+  OSD_TRY(wg(W.f.out[last], Hl, Hl, d_out, D, D, n, grads[pm.out_w], Hl));
   OSD_TRY(fork());
-  OSD_HIP(wgrad(s2, W, W.f.out[last], Hl, Hl, d_out, D, D, n, grads[pm.out_w], Hl, grp));
   OSD_HIP(launch_colsum(s2, d_out, D, n, D, grads[pm.out_b]));
   OSD_TRY(record());
   OSD_HIP(dgrad(s, h->params[pm.out_w], Hl, Hl, d_out, D, D, n, W.g_out[last], Hl, false));
@@ -219,8 +226,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     ga.gz = W.g_z2[b]; ga.dgamma = grads[l2.gamma]; ga.dbeta = grads[l2.beta]; ga.dbias = grads[l2.b];
     ga.rows = n; ga.C = C; ga.drop_mode = 0; ga.partials = W.partials; ga.atomic_cols = 1;
     OSD_HIP(launch_gn_silu_bwd(s, l2.gw, ga));
-    OSD_TRY(fork());
-    OSD_HIP(wgrad(s2, W, W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C, grp));
+    OSD_TRY(wg(W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C));
     OSD_HIP(dgrad(s, h->params[l2.w], C, C, W.g_z2[b], C, C, n, W.g_mid[b], C, false));
     // first half (dropout sits behind it)
     GnBwdArgs gb{};
@@ -231,17 +237,16 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     gb.mask = (drop && masks) ? masks[b] : nullptr; gb.keep_scale = keep_scale; gb.p_drop = h->cfg.dropout_p;
     gb.seed = seed; gb.row_offset = roff; gb.step = 0; gb.tag = TAG_DROPOUT + (uint32_t)b;
     OSD_HIP(launch_gn_silu_bwd(s, l1.gw, gb));
-    OSD_TRY(fork());
     const int Kt = l1.K1 + l1.K2;
     const float* xin = (b == 0) ? W.f.h0 : W.f.out[b - 1];
-    OSD_HIP(wgrad(s2, W, xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt, grp));
+    OSD_TRY(wg(xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt));
     int skip_block = -1;
     if (l1.K2 > 0) {
       skip_block = a.n_enc - 1 - (b - a.n_enc - 1);
-      OSD_HIP(wgrad(s2, W, W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt, grp));
+      OSD_TRY(wg(W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt));
     }
     OSD_TRY(record());
-    if (b == a.n_enc) OSD_TRY(flush());          // decoder blocks + bottleneck done: first half of the weight gradients
+    if (b == a.n_enc) OSD_TRY(flush(true));          // decoder blocks + bottleneck done: first half of the weight gradients
     // dgrad into the producer of the main input; encoder outputs already hold their skip gradient
     float* gdst = (b == 0) ? W.g_h0 : W.g_out[b - 1];
     const bool acc = (b >= 1) && (b - 1 < a.n_enc);
@@ -249,26 +254,26 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     if (l1.K2 > 0) OSD_HIP(dgrad(s, h->params[l1.w] + l1.K1, Kt, l1.K2, W.g_z1[b], C, C, n, W.g_out[skip_block], l1.K2, false));
   }
   // input_proj, time_proj, cond_proj, ConditionalEmbedding  (h0 = x W^T + b + t_emb[t] + c_proj)
-  OSD_TRY(fork());
   if (dx_t) OSD_HIP(dgrad(s, h->params[pm.in_w], D, D, W.g_h0, a.H0, a.H0, n, dx_t, D, false));
-  OSD_HIP(wgrad(s2, W, x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D, grp));
-  OSD_HIP(wgrad(s2, W, W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64, grp));
+  OSD_TRY(wg(x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D));
+  OSD_TRY(wg(W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64));
+  OSD_TRY(fork());
   OSD_HIP(launch_colsum(s2, W.g_h0, a.H0, n, a.H0, grads[pm.in_b]));
   OSD_HIP(hipMemcpyAsync(grads[pm.cp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s2));
   OSD_HIP(hipMemcpyAsync(grads[pm.tp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s2));
   OSD_HIP(launch_scatter_rows(s, W.g_h0, t_idx, n, a.H0, W.g_temb));
   OSD_HIP(dgrad(s, h->params[pm.cp_w], 64, 64, W.g_h0, a.H0, a.H0, n, W.g_ce2, 64, false));
+  OSD_TRY(wg(h->d_time_emb, a.time_dim, a.time_dim, W.g_temb, a.H0, a.H0, a.T, grads[pm.tp_w], a.time_dim));
+  OSD_TRY(wg(W.f.ce1, 64, 64, W.g_ce2, 64, 64, n, grads[pm.ce2_w], 64));
   OSD_TRY(fork());
-  OSD_HIP(wgrad(s2, W, h->d_time_emb, a.time_dim, a.time_dim, W.g_temb, a.H0, a.H0, a.T, grads[pm.tp_w], a.time_dim));
-  OSD_HIP(wgrad(s2, W, W.f.ce1, 64, 64, W.g_ce2, 64, 64, n, grads[pm.ce2_w], 64, grp));
   OSD_HIP(launch_colsum(s2, W.g_ce2, 64, n, 64, grads[pm.ce2_b]));
   OSD_HIP(dgrad(s, h->params[pm.ce2_w], 64, 64, W.g_ce2, 64, 64, n, W.g_ce1, 64, false));
   OSD_HIP(launch_silu_bwd(s, W.u0, W.g_ce1, W.g_u, n * 64));
+  OSD_TRY(wg(cond, a.cond_dim, a.cond_dim, W.g_u, 64, 64, n, grads[pm.ce0_w], a.cond_dim));
   OSD_TRY(fork());
-  OSD_HIP(wgrad(s2, W, cond, a.cond_dim, a.cond_dim, W.g_u, 64, 64, n, grads[pm.ce0_w], a.cond_dim));
   OSD_HIP(launch_colsum(s2, W.g_u, 64, n, 64, grads[pm.ce0_b]));
   OSD_TRY(record());
-  OSD_TRY(flush());
+  OSD_TRY(flush(false));
   if (s2 != s) {                      // join: the caller's stream owns every result again
     hipEvent_t e;
     OSD_TRY(next_event(&e));

@@ -35,14 +35,17 @@ struct WgReduce {
 constexpr int WG_BK = 32;
 constexpr int WG_LDS_BYTES = 2 * 2 * WG_BK * 128 * 4;     // two stages of (A, B) [32][128] fp32
 
-__global__ __launch_bounds__(NTHREADS, 2) void wgrad_group_kernel(const WgItem* __restrict__ items) {
+// A workgroup runs items blockIdx.x, blockIdx.x + gridDim.x, ...: one item each when the grid covers the list, or a walk
+// over it when the host caps the grid (to leave CU slots to a concurrent stream).
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_group_kernel(const WgItem* __restrict__ items, int n_items) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TILE = WG_BK * 128;
   float* As0 = smem;
   float* As1 = smem + TILE;
   float* Bs0 = smem + 2 * TILE;
   float* Bs1 = smem + 3 * TILE;
-  const WgItem& it = items[blockIdx.x];
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+  const WgItem it = items[item];            // by value: the DMA asm statements clobber "memory"
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -116,6 +119,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_group_kernel(const WgItem* 
           *reinterpret_cast<float4*>(it.out + (size_t)p * it.ldo + f) =
               make_float4(acc[fb][pb][4 * q], acc[fb][pb][4 * q + 1], acc[fb][pb][4 * q + 2], acc[fb][pb][4 * q + 3]);
       }
+  __syncthreads();                          // the next item restages buffer 0
+  }
 }
 
 // out[p][f] = sum over slices (fixed order) of the dense slabs; one grid row per tensor

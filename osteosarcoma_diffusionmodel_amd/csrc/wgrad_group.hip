@@ -36,11 +36,21 @@ void wgrad_group_free(osd_handle* h) {
   h->wg_plans.clear();
 }
 
+// field-wise (the structs have padding bytes, so memcmp would report a change on every step and force the re-upload)
+static bool same(const WgItem& a, const WgItem& b) {
+  return a.A == b.A && a.lda == b.lda && a.B == b.B && a.ldb == b.ldb && a.F == b.F && a.P == b.P && a.f0 == b.f0 && a.p0 == b.p0 &&
+         a.k0 == b.k0 && a.k1 == b.k1 && a.out == b.out && a.ldo == b.ldo;
+}
+static bool same(const WgReduce& a, const WgReduce& b) {
+  return a.out == b.out && a.ldo == b.ldo && a.slab == b.slab && a.stride == b.stride && a.P == b.P && a.F == b.F && a.n_slices == b.n_slices;
+}
+
 template <class V, class D>
 static int upload(hipStream_t s, const V& fresh, V& kept, D** dev, size_t* cap) {
   typedef typename V::value_type E;
-  const bool same = fresh.size() == kept.size() && (fresh.empty() || memcmp(fresh.data(), kept.data(), fresh.size() * sizeof(E)) == 0) && *dev;
-  if (same) return OSD_OK;
+  bool unchanged = fresh.size() == kept.size() && *dev;
+  for (size_t i = 0; unchanged && i < fresh.size(); ++i) unchanged = same(fresh[i], kept[i]);
+  if (unchanged) return OSD_OK;
   OSD_HIP(hipStreamSynchronize(s));            // rare (first step, or the batch / tensors changed): the old list may still be in use
   if (*cap < fresh.size()) {
     if (*dev) OSD_HIP(hipFree(*dev));
@@ -55,7 +65,9 @@ static int upload(hipStream_t s, const V& fresh, V& kept, D** dev, size_t* cap) 
 }
 
 // Launch every pending weight gradient as one grouped GEMM (+ one slab reduction) on stream s.
-int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::vector<WgPending>& pend, float* slabs, int64_t slab_floats) {
+// max_grid > 0: at most that many workgroups walk the list (one slot per CU stays free for the kernels of another stream)
+int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::vector<WgPending>& pend, float* slabs, int64_t slab_floats,
+                      int max_grid) {
   if (pend.empty()) return OSD_OK;
   while ((int)h->wg_plans.size() <= plan_index) h->wg_plans.push_back(new WgPlanDev());
   WgPlanDev* pl = static_cast<WgPlanDev*>(h->wg_plans[plan_index]);
@@ -99,7 +111,9 @@ int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::v
   std::stable_sort(items.begin(), items.end(), [](const WgItem& a, const WgItem& b) { return (a.k1 - a.k0) > (b.k1 - b.k0); });
   OSD_TRY(upload(s, items, pl->items, &pl->d_items, &pl->cap_items));
   OSD_TRY(upload(s, reds, pl->reds, &pl->d_reds, &pl->cap_reds));
-  hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)pl->items.size()), dim3(NTHREADS), WG_LDS_BYTES, s, pl->d_items);
+  const int n_items = (int)pl->items.size();
+  const int grid = max_grid > 0 ? std::min(n_items, max_grid) : n_items;
+  hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)grid), dim3(NTHREADS), WG_LDS_BYTES, s, pl->d_items, n_items);
   OSD_HIP(hipGetLastError());
   if (!pl->reds.empty()) {
     hipLaunchKernelGGL(wgrad_group_reduce, dim3(64, (unsigned)pl->reds.size()), dim3(256), 0, s, pl->d_reds);

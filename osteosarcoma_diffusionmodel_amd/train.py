@@ -61,9 +61,14 @@ class FlatParams:
                 p.grad = gv
                 self.grad_views.append(gv)
 
-    def is_current(self) -> bool:
+    def is_current(self, quick: bool = False) -> bool:
+        """True while the parameters still live in the flat buffer.  ``quick`` checks the first and the last parameter only
+        (what ``model.to()`` / ``load`` re-allocations change together with all the others): the per-step guard."""
         base = self.flat.data_ptr()
-        return all(p.data_ptr() == base + 4 * int(o) for p, o in zip(self.params, self.offsets[:-1]))
+        pairs = list(zip(self.params, self.offsets[:-1]))
+        if quick:
+            pairs = [pairs[0], pairs[-1]]
+        return all(p.data_ptr() == base + 4 * int(o) for p, o in pairs)
 
     def slice_of(self, first: int, last: int) -> torch.Tensor:
         """Flat gradient slice covering parameters first..last (inclusive)."""
@@ -71,9 +76,15 @@ class FlatParams:
 
 
 def _loss_fwd_bwd(model: BiologyAwareDiffusionModel, x0, cond, grad_ptrs, *, t=None, noise=None, dropout_masks=None,
-                  seed=None, row_offset=0, loss_scale=1.0, events=None) -> torch.Tensor:
-    """One call of osd_train_loss_fwd_bwd; returns the 1-element device loss tensor."""
-    eng = model._engine()
+                  seed=None, row_offset=0, loss_scale=1.0, events=None, engine=None) -> torch.Tensor:
+    """One call of osd_train_loss_fwd_bwd; returns the 1-element device loss tensor.  ``engine``: the Trainer hands over
+    its engine, whose parameter pointers are the flat buffer's views (checked by the Trainer), so the per-call option /
+    signature round of ``model._engine()`` is skipped; the call itself re-derives the tables that follow the weights."""
+    if engine is None:
+        eng = model._engine()
+    else:
+        eng = engine
+        L.check(L.lib().osd_set_stream(eng.handle, C.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)))
     x0 = model._prep(x0, model.data_dim, "x_0")
     cond = model._prep(cond, model.condition_dim, "conditions")
     n = x0.shape[0]
@@ -277,15 +288,25 @@ class MixupAugmentation:
     def __init__(self, alpha: float = 0.2, model: Optional[BiologyAwareDiffusionModel] = None):
         self.alpha = alpha
         self.model = model
+        self._ring: list = []          # pinned host buffers for the permutation: an H2D copy from pageable memory would make the
+        self._ring_i = 0               # host wait for the whole previous step every iteration
 
     def __call__(self, batch):
         data, conditions, survival = batch["data"], batch["conditions"], batch["survival"]
         n = data.size(0)
         lam = np.random.beta(self.alpha, self.alpha) if self.alpha > 0 else 1.0
-        index = torch.randperm(n)
         if not data.is_cuda:
             raise RuntimeError("MixupAugmentation runs on the device: pass ROCm tensors (there is no CPU fallback)")
-        perm = index.to(data.device)
+        if not self._ring or self._ring[0][0].numel() != n:
+            self._ring = [(torch.empty(n, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+            self._ring_i = 0
+        host, ev = self._ring[self._ring_i]
+        self._ring_i = (self._ring_i + 1) % len(self._ring)
+        ev.synchronize()               # the copy that last used this buffer (4 steps ago) has finished
+        torch.randperm(n, out=host)    # the reference's draw (utils/train.py:113), on the host generator
+        perm = torch.empty(n, dtype=torch.int64, device=data.device)
+        perm.copy_(host, non_blocking=True)
+        ev.record()
         d = data.float().contiguous()
         c = conditions.float().contiguous()
         s = survival.float().contiguous()
@@ -362,6 +383,8 @@ class Trainer:
         self._events = None
         self._comm_stream = None
         self._rccl = None
+        self._engine = None if self.is_vae else self.model._engine()      # pointers = the flat buffer's views from here on
+        self._ev_ptrs = None
         import os
         self.comm_kind = (comm or os.environ.get("OSD_COMM", "torch")).lower()
         if self.comm_kind not in ("torch", "rccl"):
@@ -402,7 +425,7 @@ class Trainer:
         """``comm_events``: an optional pair of timing ``torch.cuda.Event``s recorded on the current stream when its own
         backward has been enqueued and again once it has waited for the gradient exchange -- their distance is the
         exposed (not overlapped) communication time of the step (bench.py)."""
-        if not self.flat.is_current():
+        if not self.flat.is_current(quick=True):
             raise RuntimeError("model parameters were re-allocated after Trainer construction (e.g. model.to()); rebuild the Trainer")
         if self.is_vae:
             # BiologyConstrainedVAE (utils/train.py:233-234): autograd over the HIP layer ops; gradients land in the
@@ -416,7 +439,7 @@ class Trainer:
             self.global_step += 1
             return loss.detach()
         loss = _loss_fwd_bwd(self.model, data, conditions, self._grad_ptrs, t=t, noise=noise, dropout_masks=dropout_masks, seed=seed,
-                             row_offset=self.rank * data.shape[0], loss_scale=1.0 / self.world, events=self._events)
+                             row_offset=self.rank * data.shape[0], loss_scale=1.0 / self.world, events=self._events, engine=self._engine)
         if comm_events is not None:
             comm_events[0].record()
         if self.dist:
