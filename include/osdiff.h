@@ -212,7 +212,9 @@ int osd_clip_adamw_step(osd_handle *h, float *param, float *grad, float *exp_avg
                         double weight_decay, double max_norm, int64_t step, float *grad_norm_out);
 
 /* The same step without a model handle (any nn.Module's flat buffers, e.g. the cVAE): normsq_ws is
- * caller-owned device scratch of 8 doubles. */
+ * caller-owned device scratch of 8 doubles, ZEROED by the caller once: the two norm accumulators in it alternate
+ * with the parity of `step` and each call zeroes the next one, so consecutive calls use consecutive steps
+ * (re-zero the scratch before a call that does not follow the previous one). */
 int osd_nn_clip_adamw_step(void *stream, int device, double *normsq_ws, float *param, float *grad,
                            float *exp_avg, float *exp_avg_sq, int64_t numel, double lr, double beta1,
                            double beta2, double eps, double weight_decay, double max_norm, int64_t step,
@@ -343,6 +345,11 @@ int osd_nn_vae_loss(void *stream, int device, const float *x_recon, const float 
  * out[rows][cols] = lam * v + (1 - lam) * v[perm]. */
 int osd_nn_mixup(void *stream, int device, const float *v, const int64_t *perm, double lam, int64_t rows,
                  int cols, float *out);
+/* The three tensors of one MixupAugmentation call (data [rows][data_cols], conditions [rows][cond_cols], survival [rows]) in
+ * ONE launch; a NULL output skips that tensor. */
+int osd_nn_mixup3(void *stream, int device, const float *data, const float *cond, const float *surv,
+                  const int64_t *perm, double lam, int64_t rows, int data_cols, int cond_cols,
+                  float *data_out, float *cond_out, float *surv_out);
 /* F.mse_loss(a, b) over `count` elements (models/cvae.py:323): loss_out dev float[1], da (may be NULL). */
 int osd_nn_mse(void *stream, int device, const float *a, const float *b, int64_t count, float *loss_out,
                float *da);

@@ -96,6 +96,7 @@ _SIGNATURES = {
                                          C.c_double, C.c_double, C.c_int64, _P]),
     "osd_nn_vae_loss": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P]),
     "osd_nn_mixup": (C.c_int, [_P, C.c_int, _P, _P, C.c_double, C.c_int64, C.c_int, _P]),
+    "osd_nn_mixup3": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_double, C.c_int64, C.c_int, C.c_int, _P, _P, _P]),
     "osd_nn_mse": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P, _P]),
     "osd_profile_step": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
     "osd_op_linear": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),

@@ -301,7 +301,9 @@ static int create_device_state(osd_handle* h) {
   OSD_HIP(hipMalloc((void**)&h->d_sqrt_ac, (size_t)T * 4));
   OSD_HIP(hipMalloc((void**)&h->d_sqrt_1m, (size_t)T * 4));
   OSD_HIP(hipMalloc((void**)&h->d_coef, (size_t)T * 4 * 4));
-  OSD_HIP(hipMalloc((void**)&h->d_time_emb, (size_t)T * a.time_dim * 4));
+  const size_t t_rows = (size_t)(T + 31) / 32 * 32;     // zero rows up to whole K steps of the grouped weight-gradient kernel (time_proj.weight)
+  OSD_HIP(hipMalloc((void**)&h->d_time_emb, t_rows * a.time_dim * 4));
+  OSD_HIP(hipMemset(h->d_time_emb, 0, t_rows * a.time_dim * 4));
   OSD_HIP(hipMalloc((void**)&h->d_temb, (size_t)T * a.H0 * 4));
   h->w_in_ld = (a.D + BK - 1) / BK * BK;
   OSD_HIP(hipMalloc((void**)&h->w_in_packed, (size_t)a.H0 * h->w_in_ld * 4));
@@ -326,7 +328,8 @@ int osd_create(const osd_config* cfg, osd_handle** out) {
   if (!h) { set_error("out of host memory"); return OSD_ENOMEM; }
   h->cfg = *cfg;
   h->arch = a;
-  if (const char* e = getenv("OSD_GROUPED_WGRAD")) h->grouped_wgrad = atoi(e) != 0;      // A/B knob, see osd_set_option
+  if (const char* e = getenv("OSD_GROUPED_WGRAD")) h->grouped_wgrad = atoi(e) != 0;      // A/B knobs, see osd_set_option
+  if (const char* e = getenv("OSD_WGRAD_MID_FLUSH")) h->wgrad_mid_flush = atoi(e) != 0;
   const int rc = create_device_state(h);
   if (rc != OSD_OK) {                 // nothing of a half-built handle survives (osd_destroy frees what was allocated)
     osd_destroy(h);
@@ -412,6 +415,11 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "grouped_wgrad")) {           // 1 (default): the weight gradients of a backward pass in two grouped launches
     if (value < 0 || value > 1) { set_error("grouped_wgrad must be 0 or 1"); return OSD_EINVAL; }
     h->grouped_wgrad = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "wgrad_mid_flush")) {         // 1: the decoder + bottleneck weight gradients are launched (one workgroup per CU)
+    if (value < 0 || value > 1) { set_error("wgrad_mid_flush must be 0 or 1"); return OSD_EINVAL; }    // while the encoder half of backward runs
+    h->wgrad_mid_flush = (int)value;
     return OSD_OK;
   }
   if (!strcmp(name, "train_streams")) {
@@ -664,9 +672,8 @@ int osd_mixup(osd_handle* h, const float* data, const float* cond, const float* 
   OSD_TRY(check_rows(n));
   if (!perm) { set_error("null perm"); return OSD_EINVAL; }
   OSD_HIP(hipSetDevice(h->cfg.device));
-  if (data && data_out) OSD_HIP(launch_mixup(h->stream, data, perm, lam, n, h->arch.D, data_out));
-  if (cond && cond_out) OSD_HIP(launch_mixup(h->stream, cond, perm, lam, n, h->arch.cond_dim, cond_out));
-  if (surv && surv_out) OSD_HIP(launch_mixup(h->stream, surv, perm, lam, n, 1, surv_out));
+  OSD_HIP(launch_mixup3(h->stream, data_out ? data : nullptr, cond_out ? cond : nullptr, surv_out ? surv : nullptr, perm, lam, n, h->arch.D,
+                        h->arch.cond_dim, data_out, cond_out, surv_out));
   return OSD_OK;
 }
 

@@ -105,6 +105,7 @@ struct osd_handle {
   int* t_san = nullptr;              // clamped copy of a caller-supplied t_index (sanitize_t)
   int64_t t_san_cap = 0;
   double* normsq_dev = nullptr;
+  int64_t last_adam_step = 0;
   // weight-gradient side stream of the backward pass and its fork/join events
   hipStream_t wgrad_stream = nullptr;
   std::vector<hipEvent_t> ev_pool;
@@ -115,6 +116,7 @@ struct osd_handle {
   double w_pathway = 0.0, w_mutexpr = 0.0;
   float* parts_dev = nullptr;
   std::vector<void*> wg_plans;       // grouped weight-gradient launches (wgrad_group.hip): one cached work list per flush point
+  int wgrad_mid_flush = 0;           // osd_set_option("wgrad_mid_flush", 0|1): also launch the decoder-half weight gradients mid-pass
   int grouped_wgrad = 1;             // osd_set_option("grouped_wgrad", 0|1)
   // persistent reverse-chain kernel (chain.h / chain.hip)
   int sampler = 0;                   // osd_set_option("sampler"): 0 auto, 1 chain kernel whenever the architecture allows, 2 per-layer kernels

@@ -49,14 +49,22 @@ hipError_t launch_copy2d(hipStream_t s, const float* src, int lds, float* dst, i
 
 // q_sample (models/diffusion.py:337-340): x_t = sqrt_ac[t]*x0 + sqrt_1m[t]*eps, two roundings of the
 // products then one add, as torch evaluates it.
+// t == null: the row's timestep is drawn here -- torch.randint(0, T, (B,)) stand-in of models/diffusion.py:361, the same Philox
+// word k_randint uses -- and written to t_out by the row's first thread.
 __global__ void k_q_sample(const float* x0, const int* t, const float* sqrt_ac, const float* sqrt_1m, const float* noise_in,
-                           int64_t rows, int cols, uint64_t seed, uint32_t row_offset, float* x_t, float* noise_out) {
+                           int64_t rows, int cols, uint64_t seed, uint32_t row_offset, float* x_t, float* noise_out, int* t_out, int T) {
   const int c4n = (cols + 3) >> 2;
   const int64_t total = rows * c4n;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / c4n;
     const int c = 4 * (int)(i - r * c4n);
-    const int tt = t[r];
+    int tt;
+    if (t) tt = t[r];
+    else {
+      const uint4 rr = philox_at(seed, row_offset + (uint32_t)r, 0u, 0u, TAG_TSTEP);
+      tt = (int)(((uint64_t)rr.x * (uint64_t)T) >> 32);
+      if (c == 0) t_out[r] = tt;
+    }
     const float a = sqrt_ac[tt], b = sqrt_1m[tt];
     const float4 x = ld4g(x0 + r * cols, c, cols);
     float4 n;
@@ -73,10 +81,11 @@ __global__ void k_q_sample(const float* x0, const int* t, const float* sqrt_ac, 
 }
 hipError_t launch_q_sample(hipStream_t s, const float* x0, const int* t, const float* sqrt_ac, const float* sqrt_1m,
                            const float* noise_in, int64_t rows, int cols, uint64_t seed, uint32_t row_offset,
-                           float* x_t, float* noise_out) {
+                           float* x_t, float* noise_out, int* t_out, int T) {
   if (rows <= 0) return hipSuccess;
+  if (!t && (!t_out || T < 1)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_q_sample, ew_grid(rows * ((cols + 3) / 4)), 256, 0, s, x0, t, sqrt_ac, sqrt_1m, noise_in, rows, cols, seed,
-                     row_offset, x_t, noise_out);
+                     row_offset, x_t, noise_out, t_out, T);
   return hipGetLastError();
 }
 
@@ -129,6 +138,39 @@ hipError_t launch_mixup(hipStream_t s, const float* v, const int64_t* perm, doub
   // python: lam and (1 - lam) are float64 scalars; torch multiplies an fp32 tensor by each as fp32
   const float oml = (float)(1.0 - lam);
   hipLaunchKernelGGL(k_mixup, ew_grid(rows * ((cols + 3) / 4)), 256, 0, s, v, perm, (float)lam, oml, rows, cols, out);
+  return hipGetLastError();
+}
+
+// the three tensors of MixupAugmentation.__call__ (data [n][D], conditions [n][cd], survival [n]) in one launch
+__global__ void k_mixup3(const float* d, const float* c, const float* sv, const int64_t* perm, float lam, float oml, int64_t rows, int D, int cd,
+                         float* od, float* oc, float* os) {
+  const int d4 = (D + 3) >> 2, c4 = (cd + 3) >> 2;
+  const int per_row = d4 + c4 + 1;
+  const int64_t total = rows * per_row;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / per_row;
+    int j = (int)(i - r * per_row);
+    const int64_t pr = perm[r];
+    const float* src; float* dst; int cols, col;
+    if (j < d4) { src = d; dst = od; cols = D; col = 4 * j; }
+    else if (j < d4 + c4) { src = c; dst = oc; cols = cd; col = 4 * (j - d4); }
+    else { src = sv; dst = os; cols = 1; col = 0; }
+    if (!src || !dst) continue;
+    const float4 a = ld4g(src + r * cols, col, cols);
+    const float4 b = ld4g(src + pr * cols, col, cols);
+    float4 o;
+    o.x = __fadd_rn(__fmul_rn(lam, a.x), __fmul_rn(oml, b.x));
+    o.y = __fadd_rn(__fmul_rn(lam, a.y), __fmul_rn(oml, b.y));
+    o.z = __fadd_rn(__fmul_rn(lam, a.z), __fmul_rn(oml, b.z));
+    o.w = __fadd_rn(__fmul_rn(lam, a.w), __fmul_rn(oml, b.w));
+    st4g(dst + r * cols, col, cols, o);
+  }
+}
+hipError_t launch_mixup3(hipStream_t s, const float* d, const float* c, const float* sv, const int64_t* perm, double lam, int64_t rows, int D,
+                         int cd, float* od, float* oc, float* os) {
+  if (rows <= 0) return hipSuccess;
+  const float oml = (float)(1.0 - lam);
+  hipLaunchKernelGGL(k_mixup3, ew_grid(rows * ((D + 3) / 4 + (cd + 3) / 4 + 1)), 256, 0, s, d, c, sv, perm, (float)lam, oml, rows, D, cd, od, oc, os);
   return hipGetLastError();
 }
 

@@ -281,24 +281,24 @@ hipError_t launch_slab_reduce(hipStream_t s, const float* slabs, int ns, int row
 
 // ---- wgrad of a Linear with very few inputs (the condition MLP, cond_dim ~ 3):
 // dW[n][k] = sum_m gz[m][n] * x[m][k], one thread per (n,k), rows split over blocks, atomics at the end
-__global__ void k_small_wgrad(const float* x, int kin, const float* gz, int ldg, int nout, int64_t rows, int rows_per_block, float* dw) {
+// dw and dbias (optional: the threads of column k == 0 also carry sum_m gz[m][n]) are ADDED to: zeroed by the caller
+__global__ void k_small_wgrad(const float* x, int kin, const float* gz, int ldg, int nout, int64_t rows, int rows_per_block, float* dw, float* dbias) {
   const int i = threadIdx.x;
   if (i >= nout * kin) return;
   const int n = i / kin, k = i - n * kin;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  float s = 0.f;
-  for (int64_t r = r0; r < r1; ++r) s += gz[r * ldg + n] * x[r * kin + k];
+  float s = 0.f, sb = 0.f;
+  for (int64_t r = r0; r < r1; ++r) { const float g = gz[r * ldg + n]; s += g * x[r * kin + k]; sb += g; }
   atomicAdd(dw + i, s);
+  if (dbias && k == 0) atomicAdd(dbias + n, sb);
 }
-hipError_t launch_small_wgrad(hipStream_t s, const float* x, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw) {
+hipError_t launch_small_wgrad(hipStream_t s, const float* x, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, float* dbias) {
   if (rows <= 0) return hipSuccess;
   if (nout * kin > 1024) return hipErrorInvalidValue;
-  hipError_t e = hipMemsetAsync(dw, 0, (size_t)nout * kin * 4, s);
-  if (e != hipSuccess) return e;
   const int rpb = 64;
-  hipLaunchKernelGGL(k_small_wgrad, (unsigned)((rows + rpb - 1) / rpb), 1024, 0, s, x, kin, gz, ldg, nout, rows, rpb, dw);
+  hipLaunchKernelGGL(k_small_wgrad, (unsigned)((rows + rpb - 1) / rpb), 1024, 0, s, x, kin, gz, ldg, nout, rows, rpb, dw, dbias);
   return hipGetLastError();
 }
 
@@ -318,9 +318,12 @@ __global__ void k_sumsq(const float* g, int64_t n, double* out) {
   if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
-__global__ void k_adamw(float* p, float* g, float* m, float* v, int64_t n, AdamArgs a, const double* normsq, float* norm_out) {
+// normsq_next: the accumulator the NEXT step's k_sumsq will add into, zeroed here (nobody touches it during this launch), so the
+// norm needs no memset launch of its own
+__global__ void k_adamw(float* p, float* g, float* m, float* v, int64_t n, AdamArgs a, const double* normsq, double* normsq_next, float* norm_out) {
   float coef = 1.0f;
   const float norm = (float)sqrt(*normsq);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *normsq_next = 0.0;
   if (a.max_norm > 0.f) {
     coef = a.max_norm / (norm + 1e-6f);
     if (coef > 1.0f) coef = 1.0f;
@@ -341,13 +344,14 @@ __global__ void k_adamw(float* p, float* g, float* m, float* v, int64_t n, AdamA
 }
 
 hipError_t launch_clip_adamw(hipStream_t s, float* p, float* g, float* m, float* v, int64_t n, const AdamArgs& a, double* normsq_ws,
-                             float* norm_out) {
+                             int64_t step, float* norm_out) {
   if (n <= 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(normsq_ws, 0, sizeof(double), s);
-  if (e != hipSuccess) return e;
+  // two accumulators used in turn (normsq_ws[step & 1]); both start at zero (the owner zeroes the workspace once)
+  double* cur = normsq_ws + (step & 1);
+  double* nxt = normsq_ws + ((step + 1) & 1);
   const int grid = ew_grid(n, 256 * 8);
-  hipLaunchKernelGGL(k_sumsq, grid, 256, 0, s, g, n, normsq_ws);
-  hipLaunchKernelGGL(k_adamw, ew_grid(n, 256 * 4), 256, 0, s, p, g, m, v, n, a, normsq_ws, norm_out);
+  hipLaunchKernelGGL(k_sumsq, grid, 256, 0, s, g, n, cur);
+  hipLaunchKernelGGL(k_adamw, ew_grid(n, 256 * 4), 256, 0, s, p, g, m, v, n, a, cur, nxt, norm_out);
   return hipGetLastError();
 }
 

@@ -30,11 +30,11 @@ struct GnBwdArgs {
 constexpr int GN_BWD_MAX_BLOCKS = 256;
 hipError_t launch_gn_silu_bwd(hipStream_t s, int gw, const GnBwdArgs& a);
 hipError_t launch_slab_reduce(hipStream_t s, const float* slabs, int ns, int rows, int cols, int64_t stride, float* out, int ldo);
-hipError_t launch_small_wgrad(hipStream_t s, const float* x, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw);
+hipError_t launch_small_wgrad(hipStream_t s, const float* x, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, float* dbias);
 
 // ---- grouped weight gradients (wgrad_group.h / wgrad_group.hip) -----------------------------------------------
 // dw[nout][kin] (leading dimension lddw) = sum over rows of gz[row][nout] * x[row][kin]
-struct WgPending { const float* x; int ldx; int kin; const float* gz; int ldg; int nout; int64_t rows; float* dw; int lddw; };
+struct WgPending { const float* x; int ldx; int kin; const float* gz; int ldg; int nout; int64_t rows; float* dw; int lddw; float* bias[3]; };
 bool wgrad_group_ok(const WgPending& w);
 
 struct AdamArgs {
@@ -44,6 +44,6 @@ struct AdamArgs {
   float max_norm;
 };
 hipError_t launch_clip_adamw(hipStream_t s, float* p, float* g, float* m, float* v, int64_t n, const AdamArgs& a, double* normsq_ws,
-                             float* norm_out);
+                             int64_t step, float* norm_out);
 
 }  // namespace osd

@@ -336,6 +336,15 @@ int osd_nn_mixup(void* stream, int device, const float* v, const int64_t* perm, 
   return OSD_OK;
 }
 
+int osd_nn_mixup3(void* stream, int device, const float* data, const float* cond, const float* surv, const int64_t* perm, double lam, int64_t rows,
+                  int data_cols, int cond_cols, float* data_out, float* cond_out, float* surv_out) {
+  if (!perm || rows < 1 || data_cols < 1 || cond_cols < 1) { set_error("bad argument"); return OSD_EINVAL; }
+  OSD_HIP(hipSetDevice(device));
+  OSD_HIP(launch_mixup3((hipStream_t)stream, data_out ? data : nullptr, cond_out ? cond : nullptr, surv_out ? surv : nullptr, perm, lam, rows,
+                        data_cols, cond_cols, data_out, cond_out, surv_out));
+  return OSD_OK;
+}
+
 int osd_nn_mse(void* stream, int device, const float* a, const float* b, int64_t count, float* loss_out, float* da) {
   if (!a || !b || !loss_out || count < 1) { set_error("bad argument"); return OSD_EINVAL; }
   OSD_HIP(hipSetDevice(device));

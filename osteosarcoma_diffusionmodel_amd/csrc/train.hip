@@ -12,6 +12,7 @@
 namespace osd {
 
 static int64_t align_up64(int64_t v) { return (v + 63) / 64 * 64; }
+static int t_pad(int T) { return (T + 31) / 32 * 32; }       // table rows padded to whole K steps of the grouped weight-gradient kernel
 
 struct TrainWs {
   FwdWs f;
@@ -38,7 +39,7 @@ static int64_t carve_train(const Arch& a, float* base, int64_t n, const ConsPlan
   w->u0 = take(n * 64);
   w->t_idx = (int*)take(n);
   w->g_h0 = take(n * a.H0); w->g_ce2 = take(n * 64); w->g_ce1 = take(n * 64); w->g_u = take(n * 64);
-  w->g_temb = take((int64_t)a.T * a.H0);
+  w->g_temb = take((int64_t)t_pad(a.T) * a.H0);
   w->g_out.resize(a.n_blocks); w->g_z2.resize(a.n_blocks); w->g_mid.resize(a.n_blocks); w->g_z1.resize(a.n_blocks);
   for (int b = 0; b < a.n_blocks; ++b) {
     const int64_t c = a.block_out[b];
@@ -64,8 +65,12 @@ static int64_t carve_train(const Arch& a, float* base, int64_t n, const ConsPlan
 // dW[n_out][k_in] = sum_m gz[m][n_out] * x[m][k_in].  The reduction runs over the batch, the output is only
 // n_out x k_in: split the batch over blockIdx.y so that ~1024 workgroups exist, each writing its partial
 // tile to a slab, then sum the slabs in a fixed order (deterministic; no float atomics).
-static hipError_t wgrad(hipStream_t s, const TrainWs& w, const float* x, int ldx, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, int lddw) {
-  if (kin <= 8 && nout * kin <= 1024 && lddw == kin) return launch_small_wgrad(s, x, kin, gz, ldg, nout, rows, dw);
+static bool small_wgrad_ok(int kin, int nout, int lddw) { return kin <= 8 && nout * kin <= 1024 && lddw == kin; }
+
+// `dbias_small`: taken by the small path only (it adds sum_m gz[m][n] into it); every other path leaves the bias to the caller
+static hipError_t wgrad(hipStream_t s, const TrainWs& w, const float* x, int ldx, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, int lddw,
+                        float* dbias_small = nullptr) {
+  if (small_wgrad_ok(kin, nout, lddw)) return launch_small_wgrad(s, x, kin, gz, ldg, nout, rows, dw, dbias_small);
   GemmArgs g{};
   g.A = x; g.lda = ldx; g.B0 = gz; g.ldb0 = ldg; g.K0 = (int)rows; g.F = kin; g.P = nout; g.K = (int)rows;
   const long tiles = (long)((kin + 63) / 64) * ((nout + 63) / 64);
@@ -124,9 +129,10 @@ static int cond_embed_fwd(osd_handle* h, hipStream_t s, const float* cond, int64
 static void add_backward_zeros(const Arch& a, const TrainWs& w, float* const* grads, ZeroList* zl) {
   const ParamMap& pm = a.pm;
   auto add = [&](float* p, int64_t c) { zl->ptr[zl->n] = p; zl->count[zl->n] = c; ++zl->n; };
-  add(w.g_temb, (int64_t)a.T * a.H0);
+  add(w.g_temb, (int64_t)t_pad(a.T) * a.H0);
   const int small[] = {pm.ce0_b, pm.ce2_b, pm.in_b, pm.cp_b, pm.tp_b, pm.out_b};
   for (int i : small) add(grads[i], pm.numel[i]);
+  if (small_wgrad_ok(a.cond_dim, 64, a.cond_dim)) add(grads[pm.ce0_w], pm.numel[pm.ce0_w]);     // k_small_wgrad adds into it
   for (const LayerDesc& l : a.layers) {          // GroupNorm backward adds its per-block column sums atomically
     add(grads[l.b], pm.numel[l.b]); add(grads[l.gamma], pm.numel[l.gamma]); add(grads[l.beta], pm.numel[l.beta]);
   }
@@ -189,11 +195,20 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   };
   // a weight gradient: deferred to the next grouped launch when eligible, else launched now on the side stream (which then
   // has to see what the main stream produced: each fork costs the main stream a few microseconds, so only then)
-  auto wg = [&](const float* x, int ldx, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, int lddw) -> int {
-    const WgPending wp{x, ldx, kin, gz, ldg, nout, rows, dw, lddw};
+  // b0..b2: bias gradients equal to the column sums of gz (the Linear's own bias and tensors that share it); they ride along
+  // with the grouped launch, with the small kernel, or -- immediate GEMM path -- take a column-sum launch
+  auto wg = [&](const float* x, int ldx, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, int lddw,
+                float* b0 = nullptr, float* b1 = nullptr, float* b2 = nullptr) -> int {
+    const WgPending wp{x, ldx, kin, gz, ldg, nout, rows, dw, lddw, {b0, b1, b2}};
     if (grp && kin >= 16 && wgrad_group_ok(wp)) { pend.push_back(wp); return OSD_OK; }
     OSD_TRY(fork());
-    OSD_HIP(wgrad(s2, W, x, ldx, kin, gz, ldg, nout, rows, dw, lddw));
+    const bool small = small_wgrad_ok(kin, nout, lddw);
+    OSD_HIP(wgrad(s2, W, x, ldx, kin, gz, ldg, nout, rows, dw, lddw, b0));
+    if (b0 && !small) OSD_HIP(launch_colsum(s2, gz, ldg, rows, nout, b0));
+    if (b0 && small && (b1 || b2)) { set_error("internal: shared bias on the small weight-gradient path"); return OSD_EINVAL; }
+    if (b0 && !small)
+      for (float* bx : {b1, b2})
+        if (bx) OSD_HIP(hipMemcpyAsync(bx, b0, (size_t)nout * 4, hipMemcpyDeviceToDevice, s2));
     return OSD_OK;
   };
   auto flush = [&](bool leave_room) -> int {
@@ -209,9 +224,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     return OSD_OK;
   };
   // output_proj
-  OSD_TRY(wg(W.f.out[last], Hl, Hl, d_out, D, D, n, grads[pm.out_w], Hl));
-  OSD_TRY(fork());
-  OSD_HIP(launch_colsum(s2, d_out, D, n, D, grads[pm.out_b]));
+  OSD_TRY(wg(W.f.out[last], Hl, Hl, d_out, D, D, n, grads[pm.out_w], Hl, grads[pm.out_b]));
   OSD_TRY(record());
   OSD_HIP(dgrad(s, h->params[pm.out_w], Hl, Hl, d_out, D, D, n, W.g_out[last], Hl, false));
 
@@ -246,7 +259,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
       OSD_TRY(wg(W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt));
     }
     OSD_TRY(record());
-    if (b == a.n_enc) OSD_TRY(flush(true));          // decoder blocks + bottleneck done: first half of the weight gradients
+    if (b == a.n_enc && h->wgrad_mid_flush) OSD_TRY(flush(true));          // decoder blocks + bottleneck done: first half of the weight gradients
     // dgrad into the producer of the main input; encoder outputs already hold their skip gradient
     float* gdst = (b == 0) ? W.g_h0 : W.g_out[b - 1];
     const bool acc = (b >= 1) && (b - 1 < a.n_enc);
@@ -255,23 +268,17 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   }
   // input_proj, time_proj, cond_proj, ConditionalEmbedding  (h0 = x W^T + b + t_emb[t] + c_proj)
   if (dx_t) OSD_HIP(dgrad(s, h->params[pm.in_w], D, D, W.g_h0, a.H0, a.H0, n, dx_t, D, false));
-  OSD_TRY(wg(x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D));
+  // h0 = x W^T + b_in + (t_emb W_t^T + b_t)[t] + (c W_c^T + b_c): the three biases share one gradient, the column sums of g_h0
+  OSD_TRY(wg(x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D, grads[pm.in_b], grads[pm.cp_b], grads[pm.tp_b]));
   OSD_TRY(wg(W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64));
-  OSD_TRY(fork());
-  OSD_HIP(launch_colsum(s2, W.g_h0, a.H0, n, a.H0, grads[pm.in_b]));
-  OSD_HIP(hipMemcpyAsync(grads[pm.cp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s2));
-  OSD_HIP(hipMemcpyAsync(grads[pm.tp_b], grads[pm.in_b], (size_t)a.H0 * 4, hipMemcpyDeviceToDevice, s2));
   OSD_HIP(launch_scatter_rows(s, W.g_h0, t_idx, n, a.H0, W.g_temb));
   OSD_HIP(dgrad(s, h->params[pm.cp_w], 64, 64, W.g_h0, a.H0, a.H0, n, W.g_ce2, 64, false));
-  OSD_TRY(wg(h->d_time_emb, a.time_dim, a.time_dim, W.g_temb, a.H0, a.H0, a.T, grads[pm.tp_w], a.time_dim));
-  OSD_TRY(wg(W.f.ce1, 64, 64, W.g_ce2, 64, 64, n, grads[pm.ce2_w], 64));
-  OSD_TRY(fork());
-  OSD_HIP(launch_colsum(s2, W.g_ce2, 64, n, 64, grads[pm.ce2_b]));
+  // both tables carry zero rows up to a multiple of 32 (whole K steps of the grouped kernel): they add nothing
+  OSD_TRY(wg(h->d_time_emb, a.time_dim, a.time_dim, W.g_temb, a.H0, a.H0, t_pad(a.T), grads[pm.tp_w], a.time_dim));
+  OSD_TRY(wg(W.f.ce1, 64, 64, W.g_ce2, 64, 64, n, grads[pm.ce2_w], 64, grads[pm.ce2_b]));
   OSD_HIP(dgrad(s, h->params[pm.ce2_w], 64, 64, W.g_ce2, 64, 64, n, W.g_ce1, 64, false));
   OSD_HIP(launch_silu_bwd(s, W.u0, W.g_ce1, W.g_u, n * 64));
-  OSD_TRY(wg(cond, a.cond_dim, a.cond_dim, W.g_u, 64, 64, n, grads[pm.ce0_w], a.cond_dim));
-  OSD_TRY(fork());
-  OSD_HIP(launch_colsum(s2, W.g_u, 64, n, 64, grads[pm.ce0_b]));
+  OSD_TRY(wg(cond, a.cond_dim, a.cond_dim, W.g_u, 64, 64, n, grads[pm.ce0_w], a.cond_dim, grads[pm.ce0_b]));
   OSD_TRY(record());
   OSD_TRY(flush(false));
   if (s2 != s) {                      // join: the caller's stream owns every result again
@@ -351,8 +358,10 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   OSD_TRY(refresh_derived(h, s));
   const int* t_idx = nullptr;
   OSD_TRY(sanitize_t(h, s, t_index, n, &t_idx));
-  if (!t_idx) { OSD_HIP(launch_randint(s, w.t_idx, n, a.T, seed, roff)); t_idx = w.t_idx; }
-  OSD_HIP(launch_q_sample(s, x0, t_idx, h->d_sqrt_ac, h->d_sqrt_1m, noise, n, D, seed, roff, w.x_t, w.noise));
+  // t ~ randint(0, T) is drawn inside q_sample (one launch less) and kept in w.t_idx for the layers that gather by it
+  int* t_draw = nullptr;
+  if (!t_idx) { t_draw = w.t_idx; t_idx = w.t_idx; }
+  OSD_HIP(launch_q_sample(s, x0, t_draw ? nullptr : t_idx, h->d_sqrt_ac, h->d_sqrt_1m, noise, n, D, seed, roff, w.x_t, w.noise, t_draw, a.T));
   const float* eps_true = noise ? noise : w.noise;
   OSD_TRY(cond_embed_fwd(h, s, cond, n, w));
   TrainWs& W = w;
@@ -483,7 +492,7 @@ static int clip_adamw(hipStream_t stream, double* normsq_ws, float* param, float
   a.eps = (float)eps;
   a.neg_step_size = (float)(-(lr / bc1));
   a.max_norm = (float)max_norm;
-  OSD_HIP(launch_clip_adamw(stream, param, grad, exp_avg, exp_avg_sq, numel, a, normsq_ws, grad_norm_out));
+  OSD_HIP(launch_clip_adamw(stream, param, grad, exp_avg, exp_avg_sq, numel, a, normsq_ws, step, grad_norm_out));
   return OSD_OK;
 }
 
@@ -492,7 +501,11 @@ int osd_clip_adamw_step(osd_handle* h, float* param, float* grad, float* exp_avg
   if (!h || !param || !grad || !exp_avg || !exp_avg_sq) { set_error("null argument"); return OSD_EINVAL; }
   if (numel <= 0 || step < 1) { set_error("numel and step must be positive"); return OSD_EINVAL; }
   OSD_HIP(hipSetDevice(h->cfg.device));
-  if (!h->normsq_dev) OSD_HIP(hipMalloc((void**)&h->normsq_dev, 64));
+  if (!h->normsq_dev) { OSD_HIP(hipMalloc((void**)&h->normsq_dev, 64)); OSD_HIP(hipMemset(h->normsq_dev, 0, 64)); h->last_adam_step = 0; }
+  // the two norm accumulators alternate with the step's parity and each launch zeroes the next one: a step that does not
+  // follow the previous one (resume, replay) finds its accumulator in an unknown state
+  if (step != h->last_adam_step + 1) OSD_HIP(hipMemsetAsync(h->normsq_dev, 0, 64, h->stream));
+  h->last_adam_step = step;
   return clip_adamw(h->stream, h->normsq_dev, param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, max_norm, step,
                     grad_norm_out);
 }

@@ -23,6 +23,9 @@ struct WgItem {
   int f0, p0;                   // tile origin
   int k0, k1;                   // row range [k0, k1), both multiples of 32
   float* out; int ldo;          // out[p][f] at out + p * ldo + f: the gradient itself or this slice's slab
+  float* bias[3];               // optional (items with f0 == 0): sum over this item's rows of gz[row][p0 + j] is ADDED (float atomics)
+                                // to bias[i][p0 + j] -- the Linear's bias gradient (and its copies), which rides along with the
+                                // weight gradient instead of taking a column-sum launch of its own; targets zeroed by the caller
 };
 
 struct WgReduce {
@@ -74,6 +77,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_group_kernel(const WgItem* 
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const bool do_bias = it.bias[0] != nullptr;                // uniform over the workgroup
+  float csum = 0.f;                                          // thread: column tid & 127 of the B tile, rows 16 * (tid >> 7) ..
 
   stage(it.k0, As0, Bs0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -102,8 +107,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_group_kernel(const WgItem* 
           for (int pb = 0; pb < 2; ++pb)
             acc[fb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[fb][e], bv[pb][e], acc[fb][pb], 0, 0, 0);
     }
+    if (do_bias) {
+      const float* col = Bc + (tid >> 7) * 16 * 128 + (tid & 127);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) csum += col[r * 128];
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+  if (do_bias) {
+    const int n = it.p0 + (tid & 127);
+    if (n < it.P) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (it.bias[i]) atomicAdd(it.bias[i] + n, csum);
+    }
   }
 
   // out[p][f]: register quad q of block (fb, pb) holds features f .. f + 3 of patient-side index p

@@ -39,7 +39,7 @@ void wgrad_group_free(osd_handle* h) {
 // field-wise (the structs have padding bytes, so memcmp would report a change on every step and force the re-upload)
 static bool same(const WgItem& a, const WgItem& b) {
   return a.A == b.A && a.lda == b.lda && a.B == b.B && a.ldb == b.ldb && a.F == b.F && a.P == b.P && a.f0 == b.f0 && a.p0 == b.p0 &&
-         a.k0 == b.k0 && a.k1 == b.k1 && a.out == b.out && a.ldo == b.ldo;
+         a.k0 == b.k0 && a.k1 == b.k1 && a.out == b.out && a.ldo == b.ldo && a.bias[0] == b.bias[0] && a.bias[1] == b.bias[1] && a.bias[2] == b.bias[2];
 }
 static bool same(const WgReduce& a, const WgReduce& b) {
   return a.out == b.out && a.ldo == b.ldo && a.slab == b.slab && a.stride == b.stride && a.P == b.P && a.F == b.F && a.n_slices == b.n_slices;
@@ -104,6 +104,7 @@ int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::v
           it.k0 = sl * per * WG_BK; it.k1 = std::min<int>((sl + 1) * per, ksteps) * WG_BK;
           if (n_slices > 1) { it.out = slab + (int64_t)sl * numel; it.ldo = w.kin; }
           else { it.out = w.dw; it.ldo = w.lddw; }
+          if (f0 == 0) { it.bias[0] = w.bias[0]; it.bias[1] = w.bias[1]; it.bias[2] = w.bias[2]; }
           items.push_back(it);
         }
   }

@@ -241,6 +241,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if len(steps) > 1:
             raise ValueError(f"FusedAdamW steps all parameters together but the loaded state has step counts {sorted(steps)}")
         self._step = steps.pop() if steps else 0
+        self._normsq.zero_()            # the norm accumulators alternate with the step's parity (include/osdiff.h)
         for st in self.state.values():
             st["step"] = torch.tensor(float(self._step))
 
@@ -313,8 +314,8 @@ class MixupAugmentation:
         od, oc, os_ = torch.empty_like(d), torch.empty_like(c), torch.empty_like(s)
         stream = C.c_void_p(torch.cuda.current_stream(data.device).cuda_stream)
         dev = data.device.index if data.device.index is not None else torch.cuda.current_device()
-        for src, dst in ((d, od), (c, oc), (s, os_)):
-            L.check(L.lib().osd_nn_mixup(stream, dev, L.ptr(src), L.ptr(perm), float(lam), n, src.numel() // n, L.ptr(dst)))
+        L.check(L.lib().osd_nn_mixup3(stream, dev, L.ptr(d), L.ptr(c), L.ptr(s), L.ptr(perm), float(lam), n, d.numel() // n, c.numel() // n,
+                                      L.ptr(od), L.ptr(oc), L.ptr(os_)))
         return {"data": od, "conditions": oc, "survival": os_}
 
 
