@@ -312,9 +312,12 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
+        evs[i][0].record()                     # current stream = the stream the chain kernel is launched on
         out, mask = step(args.warmup + i)
+        evs[i][1].record()
     fence()
     elapsed = max(time.perf_counter() - t0, 1e-9)
     if dist is not None:
@@ -329,8 +332,9 @@ def main():
     engine_used = model.last_sampler if hasattr(model, "last_sampler") else "graph"
 
     roof, cpu = None, None
+    sample_ms = [a.elapsed_time(b) for a, b in evs] if args.steps else []
     if rank == 0:
-        roof = roofline_leg(model, args, cond, offset, dev, engine_used)
+        roof = roofline_leg(model, args, cond, offset, dev, engine_used, sample_ms, step)
     train = None
     if not args.no_train and not args.profile_only:
         train = train_leg(dev, dist, world, rank, args.train_steps, backend)
@@ -359,13 +363,33 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline_leg(model, args, cond, offset, dev, engine_used):
-    """Per-kernel durations with HIP events on the launch stream, same process, same shapes as the timed region."""
+def roofline_leg(model, args, cond, offset, dev, engine_used, sample_ms, step_fn):
+    """The dominant kernel of the timed region, measured live with HIP events on its launch stream.
+
+    chain engine: ONE kernel (chain_kernel) runs the whole T-step reverse sample of the rank's patients, so its launch
+    duration is the event pair around sample() in the timed region (the conditioning GEMMs and the x_T fill that precede it
+    on the same stream are < 0.1 % of it) and its algorithmic work is patients x T x 5 193 728 FLOP.
+    per-layer engine: 12 launches per step; per-launch durations from osd_profile_step (eager launches on the handle's
+    stream), the dominant class being the 512-wide Linear+GroupNorm+SiLU launches."""
     import numpy as np
     import torch
     from osteosarcoma_diffusionmodel_amd import _lib as L
     eng = model._engine()
-    # rows per launch of the per-layer path: equal chunks of at most chunk_rows, whole 128-row tiles
+    T = CONF["model"]["diffusion"]["num_steps"]
+    traffic_files = [ROOT / "profiles" / n for n in ("r02_traffic.json", "r01_traffic.json")]
+
+    def traffic_for(key, scale_units):
+        for tj in traffic_files:
+            if tj.exists():
+                t = json.loads(tj.read_text())
+                ent = t.get("traffic_bytes_per_launch", {}).get(key)
+                if ent is not None:
+                    per_unit = ent / t["units_per_launch"][key] if "units_per_launch" in t else ent / t["rows_per_launch"]
+                    return round(per_unit * scale_units), (f"profiles/{tj.name}: rocprofv3 --pmc passes of an EARLIER run of this kernel "
+                                                           f"(2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), scaled by work; not measured in this run")
+        return None, None
+
+    # ---- per-layer engine: per-launch table (also reported when the chain engine is the default: it is the fallback path) ----
     chunk_cap = model.sample_chunk_rows or 65536
     n_chunks = -(-args.patients // chunk_cap)
     chunk_rows = min(args.patients, (-(-args.patients // n_chunks) + 127) // 128 * 128)
@@ -384,28 +408,45 @@ def roofline_leg(model, args, cond, offset, dev, engine_used):
     wide = [i for i in range(1, ne - 1) if launches[i]["launch"] in ("block0.first", "block0.second", "block3.first", "block3.second")]
     dom_ms = float(np.mean([ms[i] for i in wide]))
     dom_fl = float(np.mean([fl[i] for i in wide]))
-    achieved = dom_fl / (dom_ms * 1e-3) / 1e12
+    layer_achieved = dom_fl / (dom_ms * 1e-3) / 1e12
     step_ms = float(sum(ms[i] for i in range(ne)))
-    traffic, traffic_source = None, None
-    for name in ("r02_traffic.json", "r01_traffic.json"):
-        tj = ROOT / "profiles" / name
-        if tj.exists():
-            t = json.loads(tj.read_text())
-            key = "GnSilu<64> glds"
-            if key in t.get("traffic_bytes_per_launch", {}):
-                traffic = round(t["traffic_bytes_per_launch"][key] * rows / t["rows_per_launch"])
-                traffic_source = f"profiles/{name} (rocprofv3 --pmc passes of an earlier run of this kernel, 2 x FETCH_SIZE + WRITE_SIZE " \
-                                 f"at {t['rows_per_launch']} rows, scaled by rows; NOT measured in this run)"
-                break
-    layer = {"bound": "mfma", "kernel": "gemm_glds_kernel<Tile<128,128,64,64>, EpiGnSilu<64>> (Linear+GroupNorm+SiLU, 512-wide layers)",
-             "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-             "traffic_gbps": None if traffic is None else round(traffic / (dom_ms * 1e-3) / 1e9, 1),
-             "avg_launch_ms": round(dom_ms, 4), "rows_per_launch": rows,
-             "whole_step": {"ms": round(step_ms, 3),
-                            "tflops": round(rows * FLOP_PER_PATIENT_STEP / (step_ms * 1e-3) / 1e12, 2)},
-             "launches": launches}
-    return layer
+    ltraffic, lsource = traffic_for("GnSilu<64> glds", rows)
+    per_layer = {"kernel": "gemm_glds_kernel<Tile<128,128,64,64>, EpiGnSilu<64>> (Linear+GroupNorm+SiLU, 512-wide layers)",
+                 "achieved": round(layer_achieved, 2), "frac": round(layer_achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                 "avg_launch_ms": round(dom_ms, 4), "rows_per_launch": rows, "traffic": ltraffic, "traffic_source": lsource,
+                 "whole_step": {"ms": round(step_ms, 3), "tflops": round(rows * FLOP_PER_PATIENT_STEP / (step_ms * 1e-3) / 1e12, 2)},
+                 "launches": launches}
+    if engine_used != "chain" or not sample_ms:
+        roof = {"bound": "mfma", "kernel": per_layer["kernel"], "achieved": per_layer["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": per_layer["frac"], "traffic": ltraffic, "traffic_source": lsource,
+                "traffic_gbps": None if ltraffic is None else round(ltraffic / (dom_ms * 1e-3) / 1e9, 1),
+                "avg_launch_ms": per_layer["avg_launch_ms"], "rows_per_launch": rows, "whole_step": per_layer["whole_step"],
+                "launches": launches}
+        return roof
+    # ---- chain engine ----
+    launch_ms = float(np.mean(sample_ms))
+    flop = float(args.patients) * T * FLOP_PER_PATIENT_STEP
+    achieved = flop / (launch_ms * 1e-3) / 1e12
+    ctraffic, csource = traffic_for("chain_kernel", args.patients * T)
+    # one step of the per-layer engine (hipGraph replay, two chunks in flight) on the same inputs, for comparison
+    keep = model.sampler
+    model.sampler = "graph"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step_fn(10_000)
+    torch.cuda.synchronize()
+    g_s = time.perf_counter() - t0
+    model.sampler = keep
+    per_layer["patients_per_s_one_step"] = round(args.patients / g_s, 1)
+    return {"bound": "mfma", "kernel": "chain_kernel (persistent: all 12 layers x all T steps of the rank's patients in one launch; "
+                                       "v_mfma_f32_32x32x2_f32, 128x128 tiles, LDS-DMA staging)",
+            "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": ctraffic, "traffic_source": csource,
+            "traffic_gbps": None if ctraffic is None else round(ctraffic / (launch_ms * 1e-3) / 1e9, 1),
+            "avg_launch_ms": round(launch_ms, 2), "launches_timed": len(sample_ms),
+            "algorithmic_flop_per_launch": flop, "patients_per_launch": args.patients, "steps_per_launch": T,
+            "algorithmic_hbm_bytes_per_launch": float(args.patients) * T * 16000,
+            "per_layer_engine": per_layer}
 
 
 if __name__ == "__main__":

@@ -100,6 +100,12 @@ __device__ __forceinline__ bool chain_wait(const unsigned* word, unsigned want, 
 // instead of being held in 96 registers from before the K loop -- the chain kernel carries its tile / layer / unit state
 // on top of the accumulators and would spill otherwise.  `out` has all 128 rows of the tile (no row guard).
 template <int GW, int NFB, int NPB>
+#ifdef CHAIN_FAKE_DMA   // timing experiment: every staging DMA reads the first 64 KB of the slot workspace (outputs are garbage)
+#define CHAIN_SRC(ptr, fake) (fake)
+#else
+#define CHAIN_SRC(ptr, fake) (ptr)
+#endif
+
 __device__ __forceinline__ void chain_gn_silu(f32x16 (&acc)[NFB][NPB], const float* __restrict__ bias, const float* __restrict__ gamma,
                                               const float* __restrict__ beta, float* __restrict__ out, int ldo, int fw, int pw, int lane, int F) {
   static_assert(GW >= 8 && NFB * 32 >= GW, "wave must own whole groups");
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
         for (int j = 0; j < 4; ++j) {
           int rg = f0n + r0 + 32 * j;
           rg = rg < Ln.F ? rg : Ln.F - 1;
-          glds16(Ln.A + (size_t)rg * Ln.lda + k4, __builtin_amdgcn_readfirstlane(la + (unsigned)j * 4096u));
+          glds16(CHAIN_SRC(Ln.A + (size_t)rg * Ln.lda + k4, ws + (rg & 63) * 64 + k4), __builtin_amdgcn_readfirstlane(la + (unsigned)j * 4096u));
         }
       }
       if (do_b) {
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
         for (int j = 0; j < 4; ++j) {
           int rg = r0 + 32 * j;
           rg = rg < rows ? rg : rows - 1;
-          glds16(bb + (size_t)rg * Ln.ld0 + k, __builtin_amdgcn_readfirstlane(lb + (unsigned)j * 4096u));
+          glds16(CHAIN_SRC(bb + (size_t)rg * Ln.ld0 + k, ws + 8192 + (rg & 63) * 64 + k4), __builtin_amdgcn_readfirstlane(lb + (unsigned)j * 4096u));
         }
       }
     };
@@ -309,11 +315,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
       const ChainLayer& L = a.L[l];
       // the K loop's operands as plain values: the DMA asm statements clobber "memory", and a field read through the argument
       // block after one of them would be re-loaded from device memory every time (measured: the K loop ran at half speed)
-      const float* const LA = L.A;
+      const gfloat_ptr LA = uniform_ptr(L.A);
       const int Llda = L.lda, LK0 = L.K0, Lld0 = L.ld0, Lld1 = L.ld1;
       const int F = L.F, K = L.K;
-      const float* B0 = (L.in0 < 0) ? a.x + (size_t)p0 * a.D : ws + L.in0;
-      const float* B1 = ws + L.in1;
+      const float* const B0g = (L.in0 < 0) ? a.x + (size_t)p0 * a.D : ws + L.in0;      // generic copies for the K-tail path
+      const float* const B1g = ws + L.in1;
+      const gfloat_ptr B0 = uniform_ptr(B0g), B1 = uniform_ptr(B1g);
       const int rowsB = (L.in0 < 0) ? P : T::BP;                // the workspace always holds a full tile
       const int nk = (K + BK - 1) / BK;
       const int nft = (F + T::BF - 1) / T::BF;
@@ -336,25 +343,56 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
         for (int fb = 0; fb < T::NFB; ++fb) { const int R = wf + 32 * fb + l31; a_rd[fb] = R * BK; a_sw[fb] = h ^ ((R >> 1) & 7); }
 #pragma unroll
         for (int pb = 0; pb < T::NPB; ++pb) { const int R = wp + 32 * pb + l31; b_rd[pb] = R * BK; b_sw[pb] = h ^ ((R >> 1) & 7); }
-        // ---- staging: direct global -> LDS DMA, XOR-swizzled 16-byte chunks (gemm_glds.h) ----
+        // ---- staging: direct global -> LDS DMA, XOR-swizzled 16-byte chunks (gemm_glds.h).  Per-lane byte offsets of the four
+        // pieces are fixed for the tile (row clamps folded in); a K step only moves the wave-uniform bases (scalar adds) ----
+        unsigned offA[4], offB[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int rg = f0 + st_row[j];
+          rg = rg < F ? rg : F - 1;
+          offA[j] = (unsigned)(rg * Llda + st_k4[j]) * 4u;
+          int rb = st_row[j];
+          rb = rb < rowsB ? rb : rowsB - 1;
+          offB[j] = (unsigned)(rb * Lld0 + st_k4[j]) * 4u;
+        }
+        int b_panel = 0;                          // which input panel offB was built for
         auto stage = [&](int k0, float* As, float* Bs, int j) {
           const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr(As) + (unsigned)wave * 1024u);
           const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(Bs) + (unsigned)wave * 1024u);
           if (j < 4) {
-            int rg = f0 + st_row[j];
-            rg = rg < F ? rg : F - 1;
-            glds16(LA + (size_t)rg * Llda + k0 + st_k4[j], __builtin_amdgcn_readfirstlane(la + (unsigned)j * 4096u));
+            glds16s(LA + __builtin_amdgcn_readfirstlane(k0), offA[j], __builtin_amdgcn_readfirstlane(la + (unsigned)j * 4096u));
           } else {
             const int jb = j - 4;
             const bool first = k0 < LK0;            // uniform: K0 is a multiple of BK (or >= K)
-            const float* bb = first ? B0 : B1;
-            const int ld = first ? Lld0 : Lld1;
             const int kend = first ? (LK0 < K ? LK0 : K) : K - LK0;
-            int k = (first ? k0 : k0 - LK0) + st_k4[jb];
-            k = k < kend - 4 ? k : kend - 4;
-            int rg = st_row[jb];
-            rg = rg < rowsB ? rg : rowsB - 1;
-            glds16(bb + (size_t)rg * ld + k, __builtin_amdgcn_readfirstlane(lb + (unsigned)jb * 4096u));
+            const int kl = first ? k0 : k0 - LK0;   // k inside the panel
+            if (kl + BK <= kend) {
+              glds16s((first ? B0 : B1) + __builtin_amdgcn_readfirstlane(kl), offB[jb], __builtin_amdgcn_readfirstlane(lb + (unsigned)jb * 4096u));
+            } else {
+              // K tail of a panel whose width is not a multiple of 32 (input_proj, K = D): per-lane clamp to valid floats; the
+              // weights are zero there, so the re-read values do not matter as long as they are finite
+              const float* bb = first ? B0g : B1g;
+              const int ld = first ? Lld0 : Lld1;
+              int k = kl + st_k4[jb];
+              k = k < kend - 4 ? k : kend - 4;
+              int rg = st_row[jb];
+              rg = rg < rowsB ? rg : rowsB - 1;
+              glds16(bb + (size_t)rg * ld + k, __builtin_amdgcn_readfirstlane(lb + (unsigned)jb * 4096u));
+            }
+          }
+        };
+        // the B offsets follow the panel: re-derived (uniform branch, four multiplies) when the K loop crosses K0
+        auto b_offsets_for = [&](int k0) {
+          const int want = k0 < LK0 ? 0 : 1;
+          if (want != b_panel) {
+            b_panel = want;
+            const int ld = want ? Lld1 : Lld0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              int rb = st_row[j];
+              rb = rb < rowsB ? rb : rowsB - 1;
+              offB[j] = (unsigned)(rb * ld + st_k4[j]) * 4u;
+            }
           }
         };
         const unsigned long long tt1 = STAMP ? __builtin_amdgcn_s_memtime() : 0;     // buffer 0 holds this tile's first K stage
@@ -374,6 +412,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
           float* Bn = (kt & 1) ? Bs0 : Bs1;
           const bool more = kt + 1 < nk;
           const int kn = (kt + 1) * BK;
+          if (more) b_offsets_for(kn);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float av[T::NFB][4], bv[T::NPB][4];

@@ -38,6 +38,33 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
+// The same piece with the address split into a wave-uniform base (SGPR pair) and a per-lane 32-bit byte offset: a K loop then
+// advances the base with two scalar adds per operand instead of recomputing a 64-bit address per lane and piece.  That
+// matters here more than elsewhere: v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate, and every VALU instruction issued
+// beside it comes out of the matrix loop's own time (an address costs ~8 VALU issues, a K step has 8 pieces per wave).
+// s_nop 4: an SGPR pair freshly written by readfirstlane / VALU may not be read as a VMEM base for 5 states.
+// a pointer every lane holds the same value of, moved to SGPRs (what an "s" asm operand needs to be provably uniform)
+// (as a GLOBAL-address-space pointer: for a generic one hipcc emits shared-aperture checks around the integer casts, and one
+// of them -- V_CMP_NE_U32 0, src_shared_base -- does not even assemble)
+typedef const __attribute__((address_space(1))) float* gfloat_ptr;
+__device__ __forceinline__ gfloat_ptr uniform_ptr(const float* p) {
+  const gfloat_ptr q = (gfloat_ptr)p;
+  const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<gfloat_ptr>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void glds16s(gfloat_ptr sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 4\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
