@@ -97,7 +97,7 @@ hipError_t launch_scatter_rows(hipStream_t s, const float* g, const int* t, int6
 //   g_z = rstd * (g_zhat - mean_g(g_zhat) - zhat*mean_g(g_zhat*zhat))
 constexpr int GN_BWD_WAVES = 16;     // waves per block: at a training batch of 4096 rows every wave owns one row (4 waves per SIMD)
 template <int GW, int NJ>
-__global__ __launch_bounds__(64 * GN_BWD_WAVES) void k_gn_silu_bwd(GnBwdArgs a) {
+__global__ __launch_bounds__(NJ <= 2 ? 64 * GN_BWD_WAVES : 32 * GN_BWD_WAVES) void k_gn_silu_bwd(GnBwdArgs a) {      // wide rows (C > 512): 8 waves, 256 VGPRs each
   extern __shared__ __attribute__((aligned(16))) float red[];      // [3][waves of the block][C]
   const int NW = blockDim.x >> 6;
   const int lane = threadIdx.x & 63;
@@ -220,7 +220,7 @@ template <int GW>
 static hipError_t gn_bwd_go(hipStream_t s, const GnBwdArgs& a) {
   const int nj = (a.C + 255) / 256;
   const int blocks = gn_bwd_blocks(a.rows);
-  const int nw = gn_bwd_waves(a.C);
+  const int nw = nj <= 2 ? gn_bwd_waves(a.C) : GN_BWD_WAVES / 2;
   const size_t lds = (size_t)3 * nw * a.C * sizeof(float);               // 96 KB at C = 512
   static bool raised[5] = {false, false, false, false, false};           // per (GW, nj) instantiation of this function template
   auto go = [&](auto kern) -> hipError_t {

@@ -102,11 +102,12 @@ hipError_t launch_gemm_glds(hipStream_t s, const GemmArgs& g0, const typename Ep
   return hipGetLastError();
 }
 
-// a_zero_padded only matters for the forward (KC x KC) layout.
-template <class T, bool AKC, bool BKC, class Epi>
+// a_zero_padded only matters for the forward (KC x KC) layout.  ALLOW_GLDS = false keeps a (tile, epilogue) pair off the
+// LDS-DMA kernel: its instantiation is then not even compiled (used for pairs that would not fit 256 VGPRs there).
+template <class T, bool AKC, bool BKC, class Epi, bool ALLOW_GLDS = true>
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, const typename Epi::Args& ea, bool a_zero_padded = false) {
   if (g.F <= 0 || g.P <= 0) return hipSuccess;
-  if constexpr (AKC && BKC) {
+  if constexpr (AKC && BKC && ALLOW_GLDS) {
     if (glds_ok(g, a_zero_padded) && Epi::fast_ok(ea, g.F)) {
       return launch_gemm_glds<T, Epi>(s, g, ea);
     }

@@ -1,27 +1,38 @@
 #!/usr/bin/env python3
-"""Aggregate the counter_collection.csv files of tools/round_pmc.sh into the per-kernel table of profiles/r01_pmc.md."""
-import csv, glob, re, sys, json, collections
-root = sys.argv[1]
+"""Aggregate the counter_collection.csv files of tools/round_pmc.sh into the per-kernel table of profiles/rNN_pmc.md and
+the traffic json bench.py reads (profiles/rNN_traffic.json).  Usage: pmc_summary.py <dir> <round tag> <chain patient-steps per launch>"""
+import csv, glob, json, collections, sys
+root, tag, chain_units = sys.argv[1], sys.argv[2], float(sys.argv[3])
 vals = collections.defaultdict(lambda: collections.defaultdict(list))     # kernel class -> counter -> per-dispatch values
 dur = collections.defaultdict(list)
+
+
 def klass(name):
+    if "chain_kernel" in name: return "chain_kernel"
+    if "wgrad_group_kernel" in name: return "wgrad_group_kernel"
     if "gemm_glds_kernel" not in name or "128, 128, 64, 64" not in name: return None
-    m = re.search(r"Epi(\w+?)(?:<(\d+), (?:true|false)>)?\s*>?\(", name.replace("osd::", ""))
     if "EpiGnSilu<32" in name: return "GnSilu<32> glds"
     if "EpiGnSilu<64" in name: return "GnSilu<64> glds"
     if "EpiInput" in name: return "Input glds"
     if "EpiPosterior" in name: return "Posterior glds"
     return None
-for f in glob.glob(root + "/*/*/*counter_collection.csv"):
+
+
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = klass(r["Kernel_Name"])
         if k is None: continue
         vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        if r["Counter_Name"] in ("GRBM_GUI_ACTIVE",):
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
             dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+
+
 def avg(k, c):
-    v = vals[k].get(c); return sum(v) / len(v) if v else float("nan")
-print("| kernel (Tile 128x128, LDS-DMA) | launches | avg ns (profiled) | mfma_busy | LDS bank conflicts | FETCH_SIZE KiB | WRITE_SIZE KiB | traffic MB/launch | L2 hit | VALU insts |")
+    v = vals[k].get(c)
+    return sum(v) / len(v) if v else float("nan")
+
+
+print("| kernel | launches | avg ms (profiled) | mfma_busy | LDS bank conflicts | FETCH_SIZE KiB | WRITE_SIZE KiB | traffic MB/launch | L2 hit | VALU insts |")
 print("|---|---|---|---|---|---|---|---|---|---|")
 traffic = {}
 for k in sorted(vals):
@@ -32,6 +43,9 @@ for k in sorted(vals):
     traffic[k] = tr
     hit, miss = avg(k, "TCC_HIT_sum"), avg(k, "TCC_MISS_sum")
     n = len(vals[k].get("GRBM_GUI_ACTIVE", []))
-    print(f"| {k} | {n} | {sum(dur[k]) / max(len(dur[k]), 1):.0f} | {busy:.3f} | {avg(k, 'SQ_LDS_BANK_CONFLICT'):.0f} | {fetch:.0f} | {write:.0f} | {tr / 1e6:.1f} | {hit / (hit + miss):.3f} | {avg(k, 'SQ_INSTS_VALU'):.0f} |")
+    print(f"| {k} | {n} | {sum(dur[k]) / max(len(dur[k]), 1) / 1e6:.3f} | {busy:.3f} | {avg(k, 'SQ_LDS_BANK_CONFLICT'):.0f} | {fetch:.0f} | {write:.0f} | "
+          f"{tr / 1e6:.1f} | {hit / (hit + miss):.3f} | {avg(k, 'SQ_INSTS_VALU'):.0f} |")
+units = {k: (chain_units if k == "chain_kernel" else 32768.0) for k in traffic}
 print()
-print("traffic_json:", json.dumps({"rows_per_launch": 32768, "traffic_bytes_per_launch": traffic, "source": "profiles/r01_pmc.md"}))
+print("traffic_json:", json.dumps({"rows_per_launch": 32768, "units_per_launch": units, "traffic_bytes_per_launch": traffic,
+                                   "unit_of": {"chain_kernel": "patient-steps", "default": "rows"}, "source": f"profiles/{tag}_pmc.md"}))
