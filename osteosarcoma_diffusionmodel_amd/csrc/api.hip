@@ -330,6 +330,7 @@ int osd_create(const osd_config* cfg, osd_handle** out) {
   h->arch = a;
   if (const char* e = getenv("OSD_GROUPED_WGRAD")) h->grouped_wgrad = atoi(e) != 0;      // A/B knobs, see osd_set_option
   if (const char* e = getenv("OSD_WGRAD_MID_FLUSH")) h->wgrad_mid_flush = atoi(e) != 0;
+  if (const char* e = getenv("OSD_FUSED_GN_BWD")) h->fused_gn_bwd = atoi(e) != 0;
   const int rc = create_device_state(h);
   if (rc != OSD_OK) {                 // nothing of a half-built handle survives (osd_destroy frees what was allocated)
     osd_destroy(h);
@@ -415,6 +416,11 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "grouped_wgrad")) {           // 1 (default): the weight gradients of a backward pass in two grouped launches
     if (value < 0 || value > 1) { set_error("grouped_wgrad must be 0 or 1"); return OSD_EINVAL; }
     h->grouped_wgrad = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "fused_gn_bwd")) {
+    if (value < 0 || value > 1) { set_error("fused_gn_bwd must be 0 or 1"); return OSD_EINVAL; }
+    h->fused_gn_bwd = (int)value;
     return OSD_OK;
   }
   if (!strcmp(name, "wgrad_mid_flush")) {         // 1: the decoder + bottleneck weight gradients are launched (one workgroup per CU)

@@ -520,6 +520,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
   if (STAMP && a.stamps && tid == 0) {
     unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
     o[0] = c_dep; o[1] = c_pro; o[2] = c_k; o[3] = c_epi; o[4] = __builtin_amdgcn_s_memtime() - c_start; o[5] = c_units;
+    o[6] = __builtin_amdgcn_s_getreg(0xF804);      // HW_REG_HW_ID: where this workgroup ran
+    o[7] = __builtin_amdgcn_s_getreg(0xF814) & 7;  // HW_REG_XCC_ID
   }
 }
 

@@ -253,6 +253,142 @@ struct EpiGnSilu {
   }
 };
 
+// ---- dgrad fused with the GroupNorm(8) + SiLU (+ dropout) BACKWARD of the layer it feeds (loss.backward(), utils/train.py:239) ----
+// The GEMM is a dgrad: acc = g = dL/d(out) of layer L, where out = dropout(silu(y)), y = zhat * gamma + beta,
+// zhat = (z - mean) * rstd (models/diffusion.py:200-204).  A lane holds one row and whole groups of it (the forward epilogue's
+// layout), so the per-(row, group) sums of the GroupNorm backward are a register sum + one lane^32 exchange and dL/dz leaves
+// the kernel directly -- no separate pass over g:
+//   gy   = g * keep * silu'(y),  gzh = gy * gamma
+//   gz   = rstd * (gzh - mean_group(gzh) - zhat * mean_group(gzh * zhat))
+// `gy` is stored too (into the buffer g would have gone to): d gamma = colsum(gy * zhat), d beta = colsum(gy) are taken from
+// it by one grouped column-sum launch per flush (k_gn_colsums); d bias = colsum(gz) rides with the weight-gradient launch.
+// g_add: a partial gradient already in the gy buffer (the skip connection's share) is added first, in place.
+template <int GW, bool DROP>
+struct EpiGnBwd {
+  static constexpr bool COUNTED_STORES = false;
+  template <class A> static __device__ __forceinline__ void slice(A&, int) {}
+  struct Args {
+    const float* z; int ldz;          // pre-norm activations of layer L  [P][F]
+    const float* stats;               // (mean, rstd) [P][F/GW][2]
+    const float* gamma; const float* beta;
+    float* gz; int ldg;               // dL/dz                            [P][F]
+    float* gy; int ldy;               // dL/dy (and, when accumulate, the incoming partial g)  [P][F]
+    int accumulate;
+    int drop_mode; const float* mask; int ldm; float keep_scale; float p_drop;
+    uint64_t seed; uint32_t row_offset; uint32_t step; uint32_t tag;
+  };
+  static bool fast_ok(const Args& a, int F) {
+    return F % 4 == 0 && F % GW == 0 && al16(a.z) && a.ldz % 4 == 0 && al16(a.gamma) && al16(a.beta) && al16(a.gz) && a.ldg % 4 == 0 &&
+           al16(a.gy) && a.ldy % 4 == 0 && (a.drop_mode != 1 || (al16(a.mask) && a.ldm % 4 == 0));
+  }
+  template <int NFB> struct Pre { float4 gamma[NFB][4], beta[NFB][4]; };
+  template <int NFB, bool FAST>
+  static __device__ __forceinline__ Pre<NFB> prefetch(const Args& a, int fw, int lane, int F) {
+    Pre<NFB> r;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = fw + 32 * fb + 8 * q + 4 * h;
+        r.gamma[fb][q] = ldq<FAST>(a.gamma, f, F);
+        r.beta[fb][q] = ldq<FAST>(a.beta, f, F);
+      }
+    return r;
+  }
+  template <int NFB, int NPB, bool FAST, class Sync = NoSync>
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P,
+                                               Sync&& sync = Sync()) {
+    static_assert(GW >= 8 && NFB * 32 >= GW, "wave must own whole groups");
+    constexpr int RPG = GW / 2;                 // registers of one group in this lane
+    constexpr int NG = NFB * 16 / RPG;
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+      const int p = pw + 32 * pb + l31;
+      const bool prow = p < P;
+      const int pc = prow ? p : P - 1;
+      const float* zrow = a.z + (size_t)pc * a.ldz;
+      float* gyrow = a.gy + (size_t)pc * a.ldy;
+      float* gzrow = a.gz + (size_t)pc * a.ldg;
+      // pass 1: gy (kept in acc), zhat recomputed in pass 2 from z; group sums
+      float zh[NFB][16];
+      float s1[NG], s2[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) s1[g] = s2[g] = 0.f;
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int f = fw + 32 * fb + 8 * q + 4 * h;
+          const int g = (fb * 16 + 4 * q) / RPG;
+          const int fc = f < F ? f : F - 4;
+          const float2 st = *reinterpret_cast<const float2*>(a.stats + ((size_t)pc * (F / GW) + fc / GW) * 2);
+          const float4 z4 = ldq<FAST>(zrow, f, F);
+          float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a.accumulate) add = ldq<FAST>(gyrow, f, F);
+          const float4 gv = pre.gamma[fb][q], bev = pre.beta[fb][q];
+          float keep[4] = {1.f, 1.f, 1.f, 1.f};
+          if (DROP && a.drop_mode == 1) {
+            const float4 mk = ldq<FAST>(a.mask + (size_t)pc * a.ldm, f, F);
+            keep[0] = mk.x * a.keep_scale; keep[1] = mk.y * a.keep_scale; keep[2] = mk.z * a.keep_scale; keep[3] = mk.w * a.keep_scale;
+          } else if (DROP && a.drop_mode == 2) {
+            const uint4 rr = philox_at(a.seed, a.row_offset + (uint32_t)p, (uint32_t)(f >> 2), a.step, a.tag);
+            keep[0] = (u01(rr.x) >= a.p_drop) ? a.keep_scale : 0.f;
+            keep[1] = (u01(rr.y) >= a.p_drop) ? a.keep_scale : 0.f;
+            keep[2] = (u01(rr.z) >= a.p_drop) ? a.keep_scale : 0.f;
+            keep[3] = (u01(rr.w) >= a.p_drop) ? a.keep_scale : 0.f;
+          }
+          const float zv[4] = {z4.x, z4.y, z4.z, z4.w};
+          const float av[4] = {add.x, add.y, add.z, add.w};
+          const float gm[4] = {gv.x, gv.y, gv.z, gv.w};
+          const float bt[4] = {bev.x, bev.y, bev.z, bev.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            const float zhat = (zv[e] - st.x) * st.y;
+            const float y = zhat * gm[e] + bt[e];
+            const float sg = 1.0f / (1.0f + expf(-y));
+            const float gyv = (acc[fb][pb][r] + av[e]) * keep[e] * (sg * (1.0f + y * (1.0f - sg)));
+            const float gzh = gyv * gm[e];
+            zh[fb][r] = zhat;
+            acc[fb][pb][r] = gyv;
+            s1[g] += gzh;
+            s2[g] += gzh * zhat;
+          }
+          if (prow) stq<FAST>(gyrow, f, F, make_float4(acc[fb][pb][4 * q], acc[fb][pb][4 * q + 1], acc[fb][pb][4 * q + 2], acc[fb][pb][4 * q + 3]));
+        }
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        s1[g] += swap_halves(s1[g]);
+        s2[g] += swap_halves(s2[g]);
+        s1[g] *= (1.0f / GW);
+        s2[g] *= (1.0f / GW);
+      }
+      // pass 2: dL/dz
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int f = fw + 32 * fb + 8 * q + 4 * h;
+          const int g = (fb * 16 + 4 * q) / RPG;
+          const int fc = f < F ? f : F - 4;
+          const float rstd = a.stats[((size_t)pc * (F / GW) + fc / GW) * 2 + 1];
+          const float4 gv = pre.gamma[fb][q];
+          const float gm[4] = {gv.x, gv.y, gv.z, gv.w};
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            o[e] = rstd * (acc[fb][pb][r] * gm[e] - s1[g] - zh[fb][r] * s2[g]);
+          }
+          if (prow) stq<FAST>(gzrow, f, F, make_float4(o[0], o[1], o[2], o[3]));
+          sync.tick();
+        }
+    }
+  }
+};
+
 // ---- output_proj fused with the DDPM posterior update (models/diffusion.py:398-425) ----
 // eps = acc + bias; the reference's x0 = (x - c0*eps)/c1, mean = c2*x0/c3 + c4*x/c3, x' = mean + c5*z
 // is linear in (x, eps, z):   x' = A_t*x + B_t*eps + C_t*z   with

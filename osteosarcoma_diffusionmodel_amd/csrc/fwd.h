@@ -35,6 +35,8 @@ void chain_free(osd_handle* h);
 struct WgPending;
 int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::vector<WgPending>& pend, float* slabs, int64_t slab_floats,
                       int max_grid);
+struct GnColItem;
+int gn_colsums_flush(osd_handle* h, hipStream_t s, int plan_index, const std::vector<GnColItem>& cols);
 void wgrad_group_free(osd_handle* h);
 int check_row_offset(int64_t row_offset, int64_t n);
 int sanitize_t(osd_handle* h, hipStream_t s, const int32_t* t_index, int64_t n, const int** out);

@@ -116,6 +116,7 @@ struct osd_handle {
   double w_pathway = 0.0, w_mutexpr = 0.0;
   float* parts_dev = nullptr;
   std::vector<void*> wg_plans;       // grouped weight-gradient launches (wgrad_group.hip): one cached work list per flush point
+  int fused_gn_bwd = 1;              // osd_set_option("fused_gn_bwd", 0|1): GroupNorm backward inside the dgrad epilogue (group widths 32 / 64)
   int wgrad_mid_flush = 0;           // osd_set_option("wgrad_mid_flush", 0|1): also launch the decoder-half weight gradients mid-pass
   int grouped_wgrad = 1;             // osd_set_option("grouped_wgrad", 0|1)
   // persistent reverse-chain kernel (chain.h / chain.hip)

@@ -37,6 +37,19 @@ hipError_t launch_small_wgrad(hipStream_t s, const float* x, int kin, const floa
 struct WgPending { const float* x; int ldx; int kin; const float* gz; int ldg; int nout; int64_t rows; float* dw; int lddw; float* bias[3]; };
 bool wgrad_group_ok(const WgPending& w);
 
+// ---- dgrad fused with the GroupNorm backward of the layer it feeds (k_gnbwd.hip, EpiGnBwd in epilogues.h) -------------
+struct GnBwdEpi {
+  const float* z; int ldz; const float* stats; const float* gamma; const float* beta;
+  float* gz; int ldg; float* gy; int ldy; int accumulate;
+  int drop_mode; const float* mask; int ldm; float keep_scale; float p_drop;
+  uint64_t seed; uint32_t row_offset; uint32_t step; uint32_t tag;
+};
+struct GemmArgs;
+bool dgrad_gnbwd_supported(int gw);
+hipError_t launch_dgrad_gnbwd(hipStream_t s, const GemmArgs& g, int gw, const GnBwdEpi& a);
+struct GnColItem { const float* gy; int ldy; const float* z; int ldz; const float* stats; int C, gw; int64_t rows; float* dgamma; float* dbeta; };
+hipError_t launch_gn_colsums(hipStream_t s, const GnColItem* d_items, int n_items, int64_t max_rows);
+
 struct AdamArgs {
   float decay;          // 1 - lr*wd
   float one_minus_b1, b2, one_minus_b2;

@@ -223,16 +223,74 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
       if (events) OSD_HIP(hipEventRecord((hipEvent_t)events[ev], s2));
     return OSD_OK;
   };
+  // GroupNorm backward: inside the epilogue of the dgrad that produces the layer's upstream gradient (group widths 32 / 64), or
+  // -- option off, other widths -- as its own pass between the GEMMs
+  bool fuse = h->fused_gn_bwd != 0;
+  for (const LayerDesc& l : a.layers) fuse = fuse && dgrad_gnbwd_supported(l.gw);
+  const float keep_scale = (float)(1.0 / (1.0 - (double)h->cfg.dropout_p));
+  std::vector<GnColItem> cols;
+  auto flush_all = [&](bool leave_room) -> int {
+    OSD_TRY(flush(leave_room));
+    if (!cols.empty()) {
+      if (!grp) OSD_TRY(fork());
+      OSD_TRY(gn_colsums_flush(h, s2, n_flush + 8, cols));      // plan slots 8.. hold the column-sum lists
+      cols.clear();
+    }
+    return OSD_OK;
+  };
+  // dgrad whose epilogue is the GroupNorm+SiLU(+dropout) backward of `ln` (z / stats of that layer): writes dL/dz and dL/dy
+  auto dgrad_fused = [&](const float* w, int ldw, int kin, const float* gz_next, int ldg, int nout, const LayerDesc& ln, const float* z,
+                         const float* stats, float* gz_out, float* gy_buf, bool accumulate, bool with_drop, int blk) -> int {
+    GemmArgs g{};
+    g.A = w; g.lda = ldw; g.B0 = gz_next; g.ldb0 = ldg; g.K0 = nout; g.F = kin; g.P = (int)n; g.K = nout;
+    GnBwdEpi e{};
+    e.z = z; e.ldz = kin; e.stats = stats; e.gamma = h->params[ln.gamma]; e.beta = h->params[ln.beta];
+    e.gz = gz_out; e.ldg = kin; e.gy = gy_buf; e.ldy = kin; e.accumulate = accumulate ? 1 : 0;
+    e.drop_mode = with_drop ? (masks ? 1 : 2) : 0;
+    e.mask = (with_drop && masks) ? masks[blk] : nullptr; e.ldm = kin; e.keep_scale = keep_scale; e.p_drop = h->cfg.dropout_p;
+    e.seed = seed; e.row_offset = roff; e.step = 0; e.tag = TAG_DROPOUT + (uint32_t)blk;
+    OSD_HIP(launch_dgrad_gnbwd(s, g, ln.gw, e));
+    cols.push_back({gy_buf, kin, z, kin, stats, kin, ln.gw, n, grads[ln.gamma], grads[ln.beta]});
+    return OSD_OK;
+  };
   // output_proj
   OSD_TRY(wg(W.f.out[last], Hl, Hl, d_out, D, D, n, grads[pm.out_w], Hl, grads[pm.out_b]));
   OSD_TRY(record());
-  OSD_HIP(dgrad(s, h->params[pm.out_w], Hl, Hl, d_out, D, D, n, W.g_out[last], Hl, false));
+  if (fuse) {
+    const LayerDesc& lz = a.layers[2 * last + 1];
+    OSD_TRY(dgrad_fused(h->params[pm.out_w], Hl, Hl, d_out, D, D, lz, W.f.z2[last], W.f.st2[last], W.g_z2[last], W.g_out[last], false, false, last));
+  } else {
+    OSD_HIP(dgrad(s, h->params[pm.out_w], Hl, Hl, d_out, D, D, n, W.g_out[last], Hl, false));
+  }
 
-  const float keep_scale = (float)(1.0 / (1.0 - (double)h->cfg.dropout_p));
   for (int b = a.n_blocks - 1; b >= 0; --b) {
     const LayerDesc& l1 = a.layers[2 * b];
     const LayerDesc& l2 = a.layers[2 * b + 1];
     const int C = l1.N;
+    const int Kt = l1.K1 + l1.K2;
+    const float* xin = (b == 0) ? W.f.h0 : W.f.out[b - 1];
+    int skip_block = -1;
+    if (l1.K2 > 0) skip_block = a.n_enc - 1 - (b - a.n_enc - 1);
+    float* gdst = (b == 0) ? W.g_h0 : W.g_out[b - 1];
+    const bool acc = (b >= 1) && (b - 1 < a.n_enc);      // encoder outputs already hold their skip gradient
+    if (fuse) {
+      // dL/dz of the second half is in g_z2[b] (left by the dgrad above it); bias gradients ride with the weight gradients
+      OSD_TRY(wg(W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C, grads[l2.b]));
+      OSD_TRY(dgrad_fused(h->params[l2.w], C, C, W.g_z2[b], C, C, l1, W.f.z1[b], W.f.st1[b], W.g_z1[b], W.g_mid[b], false, drop, b));
+      OSD_TRY(wg(xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt, grads[l1.b]));
+      if (l1.K2 > 0) OSD_TRY(wg(W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt));
+      OSD_TRY(record());
+      if (b == a.n_enc && (h->wgrad_mid_flush || events)) OSD_TRY(flush_all(true));
+      if (b == 0) {
+        OSD_HIP(dgrad(s, h->params[l1.w], Kt, l1.K1, W.g_z1[b], C, C, n, gdst, l1.K1, false));
+      } else {
+        const LayerDesc& lp = a.layers[2 * (b - 1) + 1];      // the layer that produced this block's main input
+        OSD_TRY(dgrad_fused(h->params[l1.w], Kt, l1.K1, W.g_z1[b], C, C, lp, W.f.z2[b - 1], W.f.st2[b - 1], W.g_z2[b - 1], W.g_out[b - 1], acc,
+                            false, b - 1));
+      }
+      if (l1.K2 > 0) OSD_HIP(dgrad(s, h->params[l1.w] + l1.K1, Kt, l1.K2, W.g_z1[b], C, C, n, W.g_out[skip_block], l1.K2, false));
+      continue;
+    }
     // second half: GroupNorm+SiLU backward, wgrad, dgrad
     GnBwdArgs ga{};
     ga.g = W.g_out[b]; ga.z = W.f.z2[b]; ga.stats = W.f.st2[b]; ga.gamma = h->params[l2.gamma]; ga.beta = h->params[l2.beta];
@@ -250,19 +308,11 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     gb.mask = (drop && masks) ? masks[b] : nullptr; gb.keep_scale = keep_scale; gb.p_drop = h->cfg.dropout_p;
     gb.seed = seed; gb.row_offset = roff; gb.step = 0; gb.tag = TAG_DROPOUT + (uint32_t)b;
     OSD_HIP(launch_gn_silu_bwd(s, l1.gw, gb));
-    const int Kt = l1.K1 + l1.K2;
-    const float* xin = (b == 0) ? W.f.h0 : W.f.out[b - 1];
     OSD_TRY(wg(xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt));
-    int skip_block = -1;
-    if (l1.K2 > 0) {
-      skip_block = a.n_enc - 1 - (b - a.n_enc - 1);
-      OSD_TRY(wg(W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt));
-    }
+    if (l1.K2 > 0) OSD_TRY(wg(W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt));
     OSD_TRY(record());
-    if (b == a.n_enc && h->wgrad_mid_flush) OSD_TRY(flush(true));          // decoder blocks + bottleneck done: first half of the weight gradients
-    // dgrad into the producer of the main input; encoder outputs already hold their skip gradient
-    float* gdst = (b == 0) ? W.g_h0 : W.g_out[b - 1];
-    const bool acc = (b >= 1) && (b - 1 < a.n_enc);
+    if (b == a.n_enc && (h->wgrad_mid_flush || events)) OSD_TRY(flush_all(true));    // decoder blocks + bottleneck done: first half of the weight gradients
+    // dgrad into the producer of the main input
     OSD_HIP(dgrad(s, h->params[l1.w], Kt, l1.K1, W.g_z1[b], C, C, n, gdst, l1.K1, acc));
     if (l1.K2 > 0) OSD_HIP(dgrad(s, h->params[l1.w] + l1.K1, Kt, l1.K2, W.g_z1[b], C, C, n, W.g_out[skip_block], l1.K2, false));
   }
@@ -280,7 +330,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   OSD_HIP(launch_silu_bwd(s, W.u0, W.g_ce1, W.g_u, n * 64));
   OSD_TRY(wg(cond, a.cond_dim, a.cond_dim, W.g_u, 64, 64, n, grads[pm.ce0_w], a.cond_dim, grads[pm.ce0_b]));
   OSD_TRY(record());
-  OSD_TRY(flush(false));
+  OSD_TRY(flush_all(false));
   if (s2 != s) {                      // join: the caller's stream owns every result again
     hipEvent_t e;
     OSD_TRY(next_event(&e));

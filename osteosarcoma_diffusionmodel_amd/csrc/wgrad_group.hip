@@ -20,6 +20,8 @@ struct WgPlanDev {
   std::vector<WgReduce> reds;
   WgItem* d_items = nullptr; size_t cap_items = 0;
   WgReduce* d_reds = nullptr; size_t cap_reds = 0;
+  std::vector<GnColItem> cols;
+  GnColItem* d_cols = nullptr; size_t cap_cols = 0;
 };
 
 static bool g_wg_attr[16] = {};
@@ -30,6 +32,7 @@ void wgrad_group_free(osd_handle* h) {
     hipError_t e = hipSuccess;
     if (pl->d_items) e = hipFree(pl->d_items);
     if (pl->d_reds) e = hipFree(pl->d_reds);
+    if (pl->d_cols) e = hipFree(pl->d_cols);
     (void)e;
     delete pl;
   }
@@ -43,6 +46,11 @@ static bool same(const WgItem& a, const WgItem& b) {
 }
 static bool same(const WgReduce& a, const WgReduce& b) {
   return a.out == b.out && a.ldo == b.ldo && a.slab == b.slab && a.stride == b.stride && a.P == b.P && a.F == b.F && a.n_slices == b.n_slices;
+}
+
+static bool same(const GnColItem& a, const GnColItem& b) {
+  return a.gy == b.gy && a.ldy == b.ldy && a.z == b.z && a.ldz == b.ldz && a.stats == b.stats && a.C == b.C && a.gw == b.gw && a.rows == b.rows &&
+         a.dgamma == b.dgamma && a.dbeta == b.dbeta;
 }
 
 template <class V, class D>
@@ -120,6 +128,18 @@ int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::v
     hipLaunchKernelGGL(wgrad_group_reduce, dim3(64, (unsigned)pl->reds.size()), dim3(256), 0, s, pl->d_reds);
     OSD_HIP(hipGetLastError());
   }
+  return OSD_OK;
+}
+
+// The GroupNorm affine gradients of the layers whose backward ran inside a dgrad epilogue since the last flush: one launch.
+int gn_colsums_flush(osd_handle* h, hipStream_t s, int plan_index, const std::vector<GnColItem>& cols) {
+  if (cols.empty()) return OSD_OK;
+  while ((int)h->wg_plans.size() <= plan_index) h->wg_plans.push_back(new WgPlanDev());
+  WgPlanDev* pl = static_cast<WgPlanDev*>(h->wg_plans[plan_index]);
+  OSD_TRY(upload(s, cols, pl->cols, &pl->d_cols, &pl->cap_cols));
+  int64_t max_rows = 0;
+  for (const GnColItem& c : cols) max_rows = std::max(max_rows, c.rows);
+  OSD_HIP(launch_gn_colsums(s, pl->d_cols, (int)pl->cols.size(), max_rows));
   return OSD_OK;
 }
 

@@ -29,3 +29,20 @@ for name, col in (("dependency wait", 0), ("tile prologue (first DMA stage)", 1)
     sh = s[:, col] / tot
     print(f"  {name:34s} {100*sh.mean():6.2f} %  (min {100*sh.min():.2f}, max {100*sh.max():.2f})   {s[:, col].mean()/s[:,5].mean():12.0f} cycles/unit")
 print(f"  kernel cycles / unit {tot.mean()/s[:,5].mean():.0f}; clock ~ {tot.mean()/dt/1e9:.2f} GHz")
+
+# placement: units completed per CU (both workgroups) and per XCD
+import collections
+hw, xcc = s[:, 6], s[:, 7]
+cu_key = [(int(x), int((h >> 8) & 0xFF)) for h, x in zip(hw, xcc)]
+per_cu = collections.defaultdict(list)
+for k, u in zip(cu_key, s[:, 5]):
+    per_cu[k].append(int(u))
+sizes = collections.Counter(len(v) for v in per_cu.values())
+tot = np.array([sum(v) for v in per_cu.values()])
+print(f"  CUs used {len(per_cu)}; workgroups per CU {dict(sizes)}; units per CU min {tot.min()} mean {tot.mean():.1f} max {tot.max()}")
+split = [abs(v[0] - v[1]) for v in per_cu.values() if len(v) == 2]
+print(f"  |difference| between the two workgroups of a CU: mean {np.mean(split):.1f} max {np.max(split)}")
+per_x = collections.defaultdict(int)
+for (x, _), v in per_cu.items():
+    per_x[x] += sum(v)
+print("  units per XCD:", dict(sorted(per_x.items())))
