@@ -201,8 +201,12 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
                 float* b0 = nullptr, float* b1 = nullptr, float* b2 = nullptr) -> int {
     const WgPending wp{x, ldx, kin, gz, ldg, nout, rows, dw, lddw, {b0, b1, b2}};
     if (grp && kin >= 16 && wgrad_group_ok(wp)) { pend.push_back(wp); return OSD_OK; }
-    OSD_TRY(fork());
     const bool small = small_wgrad_ok(kin, nout, lddw);
+    if (small && !events) {            // a 20 us kernel whose inputs are on the main stream: run it there, beside the side stream's GEMM
+      OSD_HIP(wgrad(s, W, x, ldx, kin, gz, ldg, nout, rows, dw, lddw, b0));
+      return OSD_OK;
+    }
+    OSD_TRY(fork());
     OSD_HIP(wgrad(s2, W, x, ldx, kin, gz, ldg, nout, rows, dw, lddw, b0));
     if (b0 && !small) OSD_HIP(launch_colsum(s2, gz, ldg, rows, nout, b0));
     if (b0 && small && (b1 || b2)) { set_error("internal: shared bias on the small weight-gradient path"); return OSD_EINVAL; }
@@ -216,7 +220,8 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     OSD_TRY(fork());                  // the side stream sees every gz produced so far
     // mid-pass flush: one workgroup per CU walks the list, the other slot of every CU stays with the dgrad chain of the
     // main stream (a full-width launch starved it: a 16 us dgrad took 104 us); the final flush has the GPU to itself
-    const int cap = (leave_room && s2 != s) ? 256 : 0;
+    static const int mid_cap = [] { const char* e = getenv("OSD_WGRAD_MID_CAP"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    const int cap = (leave_room && s2 != s) ? mid_cap : 0;
     OSD_TRY(wgrad_group_flush(h, s2, n_flush++, pend, W.slabs, W.slab_floats, cap));
     pend.clear();
     for (; ev < ev_closed; ++ev)
@@ -226,17 +231,20 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   // GroupNorm backward: inside the epilogue of the dgrad that produces the layer's upstream gradient (group widths 32 / 64), or
   // -- option off, other widths -- as its own pass between the GEMMs
   bool fuse = h->fused_gn_bwd != 0;
+  fuse = fuse && grp != nullptr;       // the fused path's bias / affine gradients ride with the grouped launches
   for (const LayerDesc& l : a.layers) fuse = fuse && dgrad_gnbwd_supported(l.gw);
   const float keep_scale = (float)(1.0 / (1.0 - (double)h->cfg.dropout_p));
   std::vector<GnColItem> cols;
   auto flush_all = [&](bool leave_room) -> int {
-    OSD_TRY(flush(leave_room));
     if (!cols.empty()) {
-      if (!grp) OSD_TRY(fork());
-      OSD_TRY(gn_colsums_flush(h, s2, n_flush + 8, cols));      // plan slots 8.. hold the column-sum lists
+      // d gamma / d beta of the layers whose backward ran in a dgrad epilogue.  Data parallel (bucket events): on the side
+      // stream AHEAD of the weight gradients, so that the events flush() records behind those cover them too.  Otherwise on
+      // the main stream, where gy / z were produced (no fork) and the memory-bound sums overlap the side stream's GEMM.
+      if (events && s2 != s) { OSD_TRY(fork()); OSD_TRY(gn_colsums_flush(h, s2, n_flush + 8, cols)); }
+      else OSD_TRY(gn_colsums_flush(h, s, n_flush + 8, cols));      // plan slots 8.. hold the column-sum lists
       cols.clear();
     }
-    return OSD_OK;
+    return flush(leave_room);
   };
   // dgrad whose epilogue is the GroupNorm+SiLU(+dropout) backward of `ln` (z / stats of that layer): writes dL/dz and dL/dy
   auto dgrad_fused = [&](const float* w, int ldw, int kin, const float* gz_next, int ldg, int nout, const LayerDesc& ln, const float* z,
