@@ -63,8 +63,9 @@ struct ChainArgs {
   unsigned* cu_arrivals;                     // [2048] zeroed per launch; null = no stagger
   int stagger;                               // shader cycles the second workgroup of a CU waits before its first unit
   unsigned long long spin_budget;            // s_memrealtime ticks (100 MHz) a dependency wait may take
-  unsigned long long* stamps;                // diagnostic (null in production): per workgroup 8 counters of shader cycles --
-                                             // dependency wait, tile prologue, K loop, epilogue + drain, whole kernel, units run
+  unsigned long long* stamps;                // diagnostic (null in production): per workgroup 32 counters of shader cycles --
+                                             // dependency wait, tile prologue, K loop, epilogue + drain, whole kernel, units run,
+                                             // placement x 2, then 6 per layer kind (see kcnt in the kernel)
 };
 
 typedef __attribute__((address_space(1))) unsigned gu32;
@@ -95,39 +96,87 @@ __device__ __forceinline__ bool chain_wait(const unsigned* word, unsigned want, 
   }
 }
 
-// Linear -> GroupNorm(8) -> SiLU epilogue on a full private tile: the arithmetic of EpiGnSilu<GW, false>::apply, operation
-// for operation (the two engines must agree bitwise), but the per-feature parameters are fetched where they are used
-// instead of being held in 96 registers from before the K loop -- the chain kernel carries its tile / layer / unit state
-// on top of the accumulators and would spill otherwise.  `out` has all 128 rows of the tile (no row guard).
-template <int GW, int NFB, int NPB>
-#ifdef CHAIN_FAKE_DMA   // timing experiment: every staging DMA reads the first 64 KB of the slot workspace (outputs are garbage)
-#define CHAIN_SRC(ptr, fake) (fake)
-#else
-#define CHAIN_SRC(ptr, fake) (ptr)
-#endif
+// ---- epilogue plumbing of the chain kernel --------------------------------------------------------------------------------
+// The MFMA fragment layout (gemm.h) gives a lane ONE row and 4 consecutive features per register quad, so a float4 store
+// straight from the accumulators touches 32 rows x 32 bytes: a quarter of a 128-byte line per row, 32 L2 write transactions per
+// wave-instruction, and the other three quarters of each line arrive with later instructions.  In-kernel stamps put 22 000 of a
+// GroupNorm tile's 31 000 epilogue cycles into issuing those 16 stores (the statistics take 600).  The chain kernel therefore
+// turns every 32-feature block through LDS -- the K loop's second operand buffer is idle during an epilogue, 8 KB per wave --
+// and stores (and loads x_t / cond_proj) as full 128-byte row segments, 8 rows per wave-instruction.
+//
+// WaveXpose: [32 * NPB rows][32 floats], 16-byte chunks XOR-swizzled by (row & 7): conflict-free for both access patterns.
+// LDS instructions of one wave execute in order, so a block's reads follow its writes (and the next block's writes follow these
+// reads) without any barrier; the compiler keeps the order because the accesses may alias.
+template <int NPB>
+struct WaveXpose {
+  float* buf;
+  // fragment side: lane (l31, h) owns row 32 pb + l31, chunk 2 q + h of the block
+  __device__ __forceinline__ void put(int pb, int q, int l31, int h, float4 v) const {
+    const int row = 32 * pb + l31;
+    *reinterpret_cast<float4*>(buf + row * 32 + 4 * ((2 * q + h) ^ (row & 7))) = v;
+  }
+  __device__ __forceinline__ float4 get(int pb, int q, int l31, int h) const {
+    const int row = 32 * pb + l31;
+    return *reinterpret_cast<const float4*>(buf + row * 32 + 4 * ((2 * q + h) ^ (row & 7)));
+  }
+  // row side: instruction i moves rows 8 i .. 8 i + 7, eight lanes per row (128 contiguous bytes)
+  template <bool GUARD>
+  __device__ __forceinline__ void store_rows(float* __restrict__ g, int ld, int lane, int rows, int cols) const {
+    const int c = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4 * NPB; ++i) {
+      const int row = 8 * i + (lane >> 3);
+      const float4 v = *reinterpret_cast<const float4*>(buf + row * 32 + 4 * (c ^ (row & 7)));
+      if (!GUARD || (row < rows && 4 * c < cols)) *reinterpret_cast<float4*>(g + (size_t)row * ld + 4 * c) = v;
+    }
+  }
+  // rows beyond `rows` / chunks beyond `cols` re-read the last valid ones (finite values that are never stored)
+  template <bool GUARD>
+  __device__ __forceinline__ void load_rows(const float* __restrict__ g, int ld, int lane, int rows, int cols) const {
+    const int c = lane & 7;
+    float4 v[4 * NPB];
+#pragma unroll
+    for (int i = 0; i < 4 * NPB; ++i) {
+      int row = 8 * i + (lane >> 3);
+      int cc = 4 * c;
+      if (GUARD) { row = row < rows ? row : rows - 1; cc = cc < cols - 4 ? cc : cols - 4; }
+      v[i] = *reinterpret_cast<const float4*>(g + (size_t)row * ld + cc);
+    }
+#pragma unroll
+    for (int i = 0; i < 4 * NPB; ++i) {
+      const int row = 8 * i + (lane >> 3);
+      *reinterpret_cast<float4*>(buf + row * 32 + 4 * (c ^ (row & 7))) = v[i];
+    }
+  }
+};
 
-__device__ __forceinline__ void chain_gn_silu(f32x16 (&acc)[NFB][NPB], const float* __restrict__ bias, const float* __restrict__ gamma,
-                                              const float* __restrict__ beta, float* __restrict__ out, int ldo, int fw, int pw, int lane, int F) {
+// Per-feature parameters of a tile in LDS: prm[0..127] bias, [128..255] gamma (input_proj: the time-embedding row), [256..383]
+// beta, for features f0 .. f0 + 127.  They arrive by DMA together with the tile's first weight stage (issued under the
+// previous tile's epilogue), so no epilogue waits for a parameter load from L2 (stamps: two round trips of ~4 500 cycles each).
+constexpr int CHAIN_PRM_FLOATS = 512;
+
+// Linear -> GroupNorm(8) -> SiLU epilogue on a full private tile: the arithmetic of EpiGnSilu<GW, false>::apply, operation
+// for operation (the two engines agree bitwise).  `fl` = first feature of the wave inside the tile, `out` = row 0 of the
+// wave's rows at feature f0 + fl of the output buffer (all 128 rows exist: no guards).
+template <int GW, int NFB, int NPB>
+__device__ __forceinline__ void chain_gn_silu(f32x16 (&acc)[NFB][NPB], const float* __restrict__ prm, int fl, float* __restrict__ out, int ldo,
+                                              const WaveXpose<NPB>& xp, int lane, unsigned long long* ts = nullptr) {
   static_assert(GW >= 8 && NFB * 32 >= GW, "wave must own whole groups");
   constexpr int RPG = GW / 2;                 // registers of one group in this lane
   constexpr int NG = NFB * 16 / RPG;
   const int l31 = lane & 31, h = lane >> 5;
-  {
-    float4 bv[NFB][4];                        // one batch of loads, one L2 round trip
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb)
+  for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bv[fb][q] = ldq<true>(bias, fw + 32 * fb + 8 * q + 4 * h, F);
+    for (int q = 0; q < 4; ++q) {
+      const float4 bv = *reinterpret_cast<const float4*>(prm + fl + 32 * fb + 8 * q + 4 * h);
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int pb = 0; pb < NPB; ++pb) {
-          acc[fb][pb][4 * q] += bv[fb][q].x; acc[fb][pb][4 * q + 1] += bv[fb][q].y;
-          acc[fb][pb][4 * q + 2] += bv[fb][q].z; acc[fb][pb][4 * q + 3] += bv[fb][q].w;
-        }
-  }
+      for (int pb = 0; pb < NPB; ++pb) {
+        acc[fb][pb][4 * q] += bv.x; acc[fb][pb][4 * q + 1] += bv.y;
+        acc[fb][pb][4 * q + 2] += bv.z; acc[fb][pb][4 * q + 3] += bv.w;
+      }
+    }
+  if (ts) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts[0] = __builtin_amdgcn_s_memtime(); }     // diagnostic builds only
   float mean[NPB][NG], rstd[NPB][NG];
 #pragma unroll
   for (int pb = 0; pb < NPB; ++pb)
@@ -145,42 +194,122 @@ __device__ __forceinline__ void chain_gn_silu(f32x16 (&acc)[NFB][NPB], const flo
       mean[pb][g] = m;
       rstd[pb][g] = 1.0f / sqrtf(qs * (1.0f / GW) + GN_EPS);
     }
+  if (ts) { asm volatile("s_nop 0" ::: "memory"); ts[1] = __builtin_amdgcn_s_memtime(); ts[2] = ts[1]; }
 #pragma unroll
   for (int fb = 0; fb < NFB; ++fb) {
-    float4 gv[4], bev[4];                     // this 32-feature block's affine parameters: one batch
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int f = fw + 32 * fb + 8 * q + 4 * h;
-      gv[q] = ldq<true>(gamma, f, F);
-      bev[q] = ldq<true>(beta, f, F);
-    }
+      const int f = fl + 32 * fb + 8 * q + 4 * h;
+      const float4 gv = *reinterpret_cast<const float4*>(prm + 128 + f);
+      const float4 bev = *reinterpret_cast<const float4*>(prm + 256 + f);
+      const int g = (fb * 16 + 4 * q) / RPG;
 #pragma unroll
-    for (int pb = 0; pb < NPB; ++pb) {
-      float* orow = out + (size_t)(pw + 32 * pb + l31) * ldo;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f = fw + 32 * fb + 8 * q + 4 * h;
-        const int g = (fb * 16 + 4 * q) / RPG;
+      for (int pb = 0; pb < NPB; ++pb) {
         const float m = mean[pb][g], r = rstd[pb][g];
         float4 y;
-        y.x = silu_f(fmaf((acc[fb][pb][4 * q] - m) * r, gv[q].x, bev[q].x));
-        y.y = silu_f(fmaf((acc[fb][pb][4 * q + 1] - m) * r, gv[q].y, bev[q].y));
-        y.z = silu_f(fmaf((acc[fb][pb][4 * q + 2] - m) * r, gv[q].z, bev[q].z));
-        y.w = silu_f(fmaf((acc[fb][pb][4 * q + 3] - m) * r, gv[q].w, bev[q].w));
-        stq<true>(orow, f, F, y);
+        y.x = silu_f(fmaf((acc[fb][pb][4 * q] - m) * r, gv.x, bev.x));
+        y.y = silu_f(fmaf((acc[fb][pb][4 * q + 1] - m) * r, gv.y, bev.y));
+        y.z = silu_f(fmaf((acc[fb][pb][4 * q + 2] - m) * r, gv.z, bev.z));
+        y.w = silu_f(fmaf((acc[fb][pb][4 * q + 3] - m) * r, gv.w, bev.w));
+        xp.put(pb, q, l31, h, y);
       }
     }
+    xp.template store_rows<false>(out + 32 * fb, ldo, lane, 0, 0);
   }
 }
 
-#ifndef CHAIN_WIDE_X
-#define CHAIN_WIDE_X false
-#endif
+// input_proj epilogue, EpiInput::apply's arithmetic: h = ((acc + b) + t_emb[t]) + c_proj.  The time-embedding row segment sits
+// in the gamma slot of the parameter block; cond_proj comes in (and h goes out) as full row segments through the transposer.
+// Rows beyond the valid ones of a partial tile hold finite copies (the host pads cproj to whole tiles) and stay private.
+template <int NFB, int NPB>
+__device__ __forceinline__ void chain_input(f32x16 (&acc)[NFB][NPB], const float* __restrict__ prm, int fl, const float* __restrict__ cproj, int ldc,
+                                            float* __restrict__ out, int ldo, const WaveXpose<NPB>& xp, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int fb = 0; fb < NFB; ++fb) {
+    xp.template load_rows<false>(cproj + 32 * fb, ldc, lane, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = fl + 32 * fb + 8 * q + 4 * h;
+      const float4 bv = *reinterpret_cast<const float4*>(prm + f);
+      const float4 tv = *reinterpret_cast<const float4*>(prm + 128 + f);
+#pragma unroll
+      for (int pb = 0; pb < NPB; ++pb) {
+        const float4 cv = xp.get(pb, q, l31, h);       // a lane reads and rewrites only its own fragment slots
+        float4 v;
+        v.x = ((acc[fb][pb][4 * q] + bv.x) + tv.x) + cv.x;
+        v.y = ((acc[fb][pb][4 * q + 1] + bv.y) + tv.y) + cv.y;
+        v.z = ((acc[fb][pb][4 * q + 2] + bv.z) + tv.z) + cv.z;
+        v.w = ((acc[fb][pb][4 * q + 3] + bv.w) + tv.w) + cv.w;
+        xp.put(pb, q, l31, h, v);
+      }
+    }
+    xp.template store_rows<false>(out + 32 * fb, ldo, lane, 0, 0);
+  }
+}
+
+// output_proj + DDPM posterior update, EpiPosterior::apply's arithmetic: x' = A_t x + B_t (acc + b) + C_t z.  `x` = the wave's
+// first row at feature f0 + fl of the chain state (read and written in place: every element is read before this wave
+// overwrites it and no other wave touches it); prow / pcol = valid rows / features from there (<= 0: nothing to do).
+template <int NFB, int NPB>
+__device__ __forceinline__ void chain_posterior(f32x16 (&acc)[NFB][NPB], const float* __restrict__ prm, int fl, float* __restrict__ x, int ldx,
+                                                int prow, int pcol, float cA, float cB, float cC, int t, const float* __restrict__ zrow, int ldzz,
+                                                uint64_t seed, uint32_t row_id0, int f_glob, float* __restrict__ mut_mask, int mutation_dim,
+                                                const WaveXpose<NPB>& xp, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+  if (prow <= 0) return;                      // uniform over the wave
+#pragma unroll
+  for (int fb = 0; fb < NFB; ++fb) {
+    const int cols = pcol - 32 * fb;          // valid features of this block
+    if (cols <= 0) break;                     // uniform
+    // x_t of the block in row segments; a lane then reads and rewrites only its own fragment slots, so each get() can sit
+    // right before its use (no 32-register copy of the block)
+    xp.template load_rows<true>(x + 32 * fb, ldx, lane, prow, cols);
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+      const int p = 32 * pb + l31;            // row inside the wave's rows
+      const int pc = p < prow ? p : prow - 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int fo = 32 * fb + 8 * q + 4 * h;           // feature offset from the wave's first
+        const float4 bv = *reinterpret_cast<const float4*>(prm + fl + fo);
+        const float e[4] = {acc[fb][pb][4 * q] + bv.x, acc[fb][pb][4 * q + 1] + bv.y, acc[fb][pb][4 * q + 2] + bv.z, acc[fb][pb][4 * q + 3] + bv.w};
+        const float4 xq = xp.get(pb, q, l31, h);
+        const float xv[4] = {xq.x, xq.y, xq.z, xq.w};
+        float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t > 0) {
+          if (zrow) {
+            const int fc = fo < pcol - 4 ? fo : pcol - 4;
+            zz = *reinterpret_cast<const float4*>(zrow + (size_t)pc * ldzz + fc);
+          } else {
+            zz = randn4(seed, row_id0 + (uint32_t)p, (uint32_t)((f_glob + fo) >> 2), (uint32_t)t, TAG_POSTERIOR);
+          }
+        }
+        const float zv[4] = {zz.x, zz.y, zz.z, zz.w};
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaf(cA, xv[r], fmaf(cB, e[r], cC * zv[r]));
+        if (t == 0 && mut_mask && p < prow && fo < pcol && f_glob + fo < mutation_dim) {
+          float* mrow = mut_mask + (size_t)p * mutation_dim;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (f_glob + fo + r < mutation_dim) mrow[f_glob + fo + r] = (o[r] > 0.5f) ? 1.0f : 0.0f;
+        }
+        xp.put(pb, q, l31, h, make_float4(o[0], o[1], o[2], o[3]));
+      }
+    }
+    xp.template store_rows<true>(x + 32 * fb, ldx, lane, prow, cols);
+  }
+}
+
 #ifndef CHAIN_EPI_PRIO
 #define CHAIN_EPI_PRIO 0
 #endif
-typedef Tile<128, 128, 64, 64> ChainTile;
-constexpr int CHAIN_LDS_BYTES = GldsTile<ChainTile>::LDS_BYTES + 16;
+typedef Tile<128, 128, 64, 64> ChainTile;            // 4 waves, 64 x 64 accumulators each (64 VGPRs), 2 waves per SIMD
+// tiles | flag word (16 B) | 40 per-kind counters of the diagnostic builds | two per-feature parameter blocks (double-buffered over tiles)
+constexpr int CHAIN_PRM_OFF = 2 * (128 * BK + 128 * BK) + 4 + 80;      // floats
+constexpr int CHAIN_LDS_BYTES = (CHAIN_PRM_OFF + 2 * CHAIN_PRM_FLOATS) * 4;
+static_assert(CHAIN_PRM_OFF % 4 == 0, "parameter blocks are read as float4");
 
 // STAMP (diagnostic builds only, make DIAG=1): per-workgroup cycle counters; the product kernel carries none of that state.
 template <bool STAMP>
@@ -191,7 +320,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
   const ChainArgs& a = *gp;
   typedef ChainTile T;
   typedef GldsTile<T> G;
-  static_assert(G::NA == 4 && G::NB == 4, "staging below assumes 4 + 4 pieces per wave");
+  static_assert(T::BF == 128 && T::BP == 128, "staging below assumes 128-row operand images");
+  constexpr int NW = NTHREADS / 64;         // waves
+  constexpr int NPW = 16 / NW;              // 1 KiB DMA pieces (8 rows x 32 k) per wave and operand: wave w moves pieces w, w + NW, ...
+  constexpr int PROWS = 8 * NW;             // rows between two pieces of a wave
+  constexpr unsigned PBYTES = 1024u * NW;   // LDS bytes between them
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As0 = smem;
   float* As1 = smem + G::A_ELEMS;
@@ -208,6 +341,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
   const int wp = (wave % T::NWP) * T::WP;
 
   float* const ws = a.ws + (long long)blockIdx.x * a.ws_stride;
+  // epilogue transposer of this wave: its share of the K loop's second operand buffers (idle between a tile's last K step and
+  // the next tile's first), 32 * NPB rows x 32 floats
+  WaveXpose<T::NPB> xp;
+  {
+    const int xo = wave * (T::NPB * 1024);
+    xp.buf = xo < G::A_ELEMS ? As1 + xo : Bs1 + (xo - G::A_ELEMS);
+  }
+  float* const prm_base = smem + CHAIN_PRM_OFF;
+  int pcur = 0;                               // parameter block of the tile being computed (uniform)
 
   // ---- stagger: the second workgroup to arrive on a CU starts `stagger` cycles late, once ----
   if (a.cu_arrivals && a.stagger > 0) {
@@ -229,6 +371,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
   }
 
   unsigned long long c_dep = 0, c_pro = 0, c_k = 0, c_epi = 0, c_units = 0;
+  // STAMP: per layer kind {K loop, epilogue until its last store is issued, store drain, barrier, layer-boundary first stage, tiles}
+  unsigned long long* const kcnt = reinterpret_cast<unsigned long long*>(smem + 2 * (G::A_ELEMS + G::B_ELEMS) + 4);
+  if constexpr (STAMP) {
+    if (tid < 40) kcnt[tid] = 0;
+    __syncthreads();
+  }
   const unsigned long long c_start = STAMP ? __builtin_amdgcn_s_memtime() : 0;
   const long long n_units = (long long)a.n_tiles * a.n_steps;
   int c_iter = 0;
@@ -275,21 +423,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
 
     // First K stage of a tile (k in [0, 32)) into LDS buffer 0: the A part (weights: no dependency, so it is issued BEFORE the
     // previous tile's epilogue and lands under it) and the B part (activations: behind the producing layer's drained stores).
-    auto first_stage = [&](const ChainLayer& Lr, int f0n, bool do_a, bool do_b) {
+    // With the A part go the tile's per-feature parameters, into parameter block `pb`: wave 0 moves bias | second array (gamma,
+    // the time-embedding row of input_proj, or bias again), wave 1 beta; 32 lanes x 16 B per array.
+    auto first_stage = [&](const ChainLayer& Lr, int f0n, bool do_a, bool do_b, int pb) {
       struct { const float* A; int lda, F, in0, ld0, K0, K; } Ln{Lr.A, Lr.lda, Lr.F, Lr.in0, Lr.ld0, Lr.K0, Lr.K};   // values, not re-loads
+      if (do_a && wave < 2) {
+        const int kind = Lr.kind;
+        const float* src = Lr.bias;
+        if (wave == 1) src = Lr.beta;
+        else if (lane >= 32) src = kind == CK_INPUT ? a.temb + (size_t)t * a.ldt : (kind == CK_POST ? Lr.bias : Lr.gamma);
+        if (wave == 0 || (kind != CK_INPUT && kind != CK_POST)) {       // uniform
+          int f = f0n + 4 * (lane & 31);
+          f = f < Ln.F - 4 ? f : Ln.F - 4;
+          glds16(src + f, __builtin_amdgcn_readfirstlane(lds_addr(prm_base + pb * CHAIN_PRM_FLOATS) + (unsigned)wave * 1024u));
+        }
+      }
       const float* const xrows = a.x + (size_t)p0 * a.D;
       int ln = lane;
       asm volatile("" : "+v"(ln));
-      const int r0 = wave * 8 + (ln >> 3);                        // piece j moves rows r0 + 32 j
-      const int k4 = 4 * ((ln & 7) ^ ((r0 >> 1) & 7));            // (row >> 1) & 7 does not depend on j
+      const int r0 = wave * 8 + (ln >> 3);                        // piece j moves rows r0 + PROWS j
+      const int k4 = 4 * ((ln & 7) ^ ((r0 >> 1) & 7));            // (row >> 1) & 7 does not depend on j (PROWS % 16 == 0)
       const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr(As0) + (unsigned)wave * 1024u);
       const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(Bs0) + (unsigned)wave * 1024u);
       if (do_a) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int rg = f0n + r0 + 32 * j;
+        for (int j = 0; j < NPW; ++j) {
+          int rg = f0n + r0 + PROWS * j;
           rg = rg < Ln.F ? rg : Ln.F - 1;
-          glds16(CHAIN_SRC(Ln.A + (size_t)rg * Ln.lda + k4, ws + (rg & 63) * 64 + k4), __builtin_amdgcn_readfirstlane(la + (unsigned)j * 4096u));
+          glds16(Ln.A + (size_t)rg * Ln.lda + k4, __builtin_amdgcn_readfirstlane(la + (unsigned)j * PBYTES));
         }
       }
       if (do_b) {
@@ -299,15 +460,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
         const int kend = Ln.K0 < Ln.K ? Ln.K0 : Ln.K;
         const int k = k4 < kend - 4 ? k4 : kend - 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int rg = r0 + 32 * j;
+        for (int j = 0; j < NPW; ++j) {
+          int rg = r0 + PROWS * j;
           rg = rg < rows ? rg : rows - 1;
-          glds16(CHAIN_SRC(bb + (size_t)rg * Ln.ld0 + k, ws + 8192 + (rg & 63) * 64 + k4), __builtin_amdgcn_readfirstlane(lb + (unsigned)j * 4096u));
+          glds16(bb + (size_t)rg * Ln.ld0 + k, __builtin_amdgcn_readfirstlane(lb + (unsigned)j * PBYTES));
         }
       }
     };
     unsigned long long tt0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
-    first_stage(a.L[0], 0, true, true);
+    first_stage(a.L[0], 0, true, true, pcur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the asm DMAs are invisible to hipcc's counters
     __syncthreads();
 
@@ -331,11 +492,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int l31 = ln & 31, h = ln >> 5;
-        // piece j of a wave moves rows 8 * (4 j + wave) .. + 7, 16 B per lane
-        int st_row[4], st_k4[4];
+        // piece j of a wave moves rows 8 * (NW j + wave) .. + 7, 16 B per lane
+        int st_row[NPW], st_k4[NPW];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          st_row[j] = (j * 4 + wave) * 8 + (ln >> 3);
+        for (int j = 0; j < NPW; ++j) {
+          st_row[j] = (j * NW + wave) * 8 + (ln >> 3);
           st_k4[j] = 4 * ((ln & 7) ^ ((st_row[j] >> 1) & 7));
         }
         int a_rd[T::NFB], a_sw[T::NFB], b_rd[T::NPB], b_sw[T::NPB];
@@ -345,9 +506,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
         for (int pb = 0; pb < T::NPB; ++pb) { const int R = wp + 32 * pb + l31; b_rd[pb] = R * BK; b_sw[pb] = h ^ ((R >> 1) & 7); }
         // ---- staging: direct global -> LDS DMA, XOR-swizzled 16-byte chunks (gemm_glds.h).  Per-lane byte offsets of the four
         // pieces are fixed for the tile (row clamps folded in); a K step only moves the wave-uniform bases (scalar adds) ----
-        unsigned offA[4], offB[4];
+        unsigned offA[NPW], offB[NPW];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NPW; ++j) {
           int rg = f0 + st_row[j];
           rg = rg < F ? rg : F - 1;
           offA[j] = (unsigned)(rg * Llda + st_k4[j]) * 4u;
@@ -359,15 +520,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
         auto stage = [&](int k0, float* As, float* Bs, int j) {
           const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr(As) + (unsigned)wave * 1024u);
           const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(Bs) + (unsigned)wave * 1024u);
-          if (j < 4) {
-            glds16s(LA + __builtin_amdgcn_readfirstlane(k0), offA[j], __builtin_amdgcn_readfirstlane(la + (unsigned)j * 4096u));
+          if (j < NPW) {
+            glds16s(LA + __builtin_amdgcn_readfirstlane(k0), offA[j], __builtin_amdgcn_readfirstlane(la + (unsigned)j * PBYTES));
           } else {
-            const int jb = j - 4;
+            const int jb = j - NPW;
             const bool first = k0 < LK0;            // uniform: K0 is a multiple of BK (or >= K)
             const int kend = first ? (LK0 < K ? LK0 : K) : K - LK0;
             const int kl = first ? k0 : k0 - LK0;   // k inside the panel
             if (kl + BK <= kend) {
-              glds16s((first ? B0 : B1) + __builtin_amdgcn_readfirstlane(kl), offB[jb], __builtin_amdgcn_readfirstlane(lb + (unsigned)jb * 4096u));
+              glds16s((first ? B0 : B1) + __builtin_amdgcn_readfirstlane(kl), offB[jb], __builtin_amdgcn_readfirstlane(lb + (unsigned)jb * PBYTES));
             } else {
               // K tail of a panel whose width is not a multiple of 32 (input_proj, K = D): per-lane clamp to valid floats; the
               // weights are zero there, so the re-read values do not matter as long as they are finite
@@ -377,7 +538,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
               k = k < kend - 4 ? k : kend - 4;
               int rg = st_row[jb];
               rg = rg < rowsB ? rg : rowsB - 1;
-              glds16(bb + (size_t)rg * ld + k, __builtin_amdgcn_readfirstlane(lb + (unsigned)jb * 4096u));
+              glds16(bb + (size_t)rg * ld + k, __builtin_amdgcn_readfirstlane(lb + (unsigned)jb * PBYTES));
             }
           }
         };
@@ -388,7 +549,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
             b_panel = want;
             const int ld = want ? Lld1 : Lld0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NPW; ++j) {
               int rb = st_row[j];
               rb = rb < rowsB ? rb : rowsB - 1;
               offB[j] = (unsigned)(rb * ld + st_k4[j]) * 4u;
@@ -435,7 +596,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
                   acc[fb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[fb][e], bv[pb][e], acc[fb][pb], 0, 0, 0);
               // the DMA of the next K tile goes out in the first quarter of the step (two pieces per k-pair group): it then
               // has three quarters of the step to land before the barrier (gemm_glds.h)
-              if (i == 0 && more) {
+              if (i == 0 && more && 2 * e < 2 * NPW) {
                 __builtin_amdgcn_sched_barrier(0);
                 stage(kn, An, Bn, 2 * e);
                 stage(kn, An, Bn, 2 * e + 1);
@@ -455,57 +616,64 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
         const bool has_next = same_layer || l + 1 < a.n_layers;
         const int ln_next = same_layer ? l : l + 1;
         const int f0_next = same_layer ? f0 + T::BF : 0;
-        if (has_next) first_stage(a.L[ln_next], f0_next, true, false);
+        if (has_next) first_stage(a.L[ln_next], f0_next, true, false, pcur ^ 1);
         const int fw = f0 + wf;
+        const float* const prm = prm_base + pcur * CHAIN_PRM_FLOATS;
+        pcur ^= 1;
         if (CHAIN_EPI_PRIO) __builtin_amdgcn_s_setprio(CHAIN_EPI_PRIO);
         const ChainArgs* ep = gp;
         asm volatile("" : "+s"(ep));          // see the kernel head: epilogue-only fields are loaded here, not at kernel entry
         const ChainArgs& e = *ep;
+        unsigned long long ets[3] = {0, 0, 0};
         if (L.kind == CK_GN64) {
-          chain_gn_silu<64, T::NFB, T::NPB>(acc, L.bias, L.gamma, L.beta, ws + L.out, L.ldo, fw, wp, lane, F);
+          chain_gn_silu<64, T::NFB, T::NPB>(acc, prm, wf, ws + L.out + (size_t)wp * L.ldo + fw, L.ldo, xp, lane, STAMP ? ets : nullptr);
         } else if (L.kind == CK_GN32) {
-          chain_gn_silu<32, T::NFB, T::NPB>(acc, L.bias, L.gamma, L.beta, ws + L.out, L.ldo, fw, wp, lane, F);
+          chain_gn_silu<32, T::NFB, T::NPB>(acc, prm, wf, ws + L.out + (size_t)wp * L.ldo + fw, L.ldo, xp, lane, STAMP ? ets : nullptr);
         } else if (L.kind == CK_INPUT) {
-          EpiInput::Args ea{L.bias, e.temb, e.ldt, nullptr, nullptr, t, e.cproj + (size_t)p0 * e.ldc, e.ldc, ws + L.out, L.ldo};
-          const EpiInput::Pre<T::NFB> pre = EpiInput::prefetch<T::NFB, true>(ea, fw, lane, F);
           // rows beyond P hold a clamped copy of the last valid row: computed and stored to the private tile like the others (the
           // host pads cproj to whole tiles), never published (the posterior epilogue stores rows < P only)
-          EpiInput::apply<T::NFB, T::NPB, true>(acc, ea, pre, fw, wp, lane, F, T::BP);
+          chain_input<T::NFB, T::NPB>(acc, prm, wf, e.cproj + (size_t)(p0 + wp) * e.ldc + fw, e.ldc, ws + L.out + (size_t)wp * L.ldo + fw, L.ldo, xp, lane);
         } else {
-          EpiPosterior::Args ea{};
-          ea.bias = L.bias;
-          ea.xin = e.x + (size_t)p0 * e.D; ea.ldx = e.D;
-          ea.xout = e.x + (size_t)p0 * e.D; ea.ldo = e.D;
-          ea.coef = e.coef; ea.t_dev = nullptr; ea.t_imm = t;
-          ea.z = e.z ? e.z + (size_t)p0 * e.ldzz : nullptr; ea.ldzz = e.ldzz; ea.z_step_stride = e.z_step_stride; ea.t_first = e.z_t_first;
-          ea.seed = e.seed; ea.row_offset = e.row_offset + (uint32_t)p0;
-          ea.mut_mask = e.mut_mask ? e.mut_mask + (size_t)p0 * e.mutation_dim : nullptr; ea.mutation_dim = e.mutation_dim;
-          const EpiPosterior::Pre<T::NFB> pre = EpiPosterior::prefetch<T::NFB, true>(ea, fw, lane, F);
-          EpiPosterior::apply<T::NFB, T::NPB, true, NoSync, CHAIN_WIDE_X>(acc, ea, pre, fw, wp, lane, F, P);
+          const float* c = e.coef + 4 * t;
+          const float cA = c[0], cB = c[1], cC = c[2];
+          const float* zrow = e.z ? e.z + (long long)(e.z_t_first - t) * e.z_step_stride + (size_t)(p0 + wp) * e.ldzz + fw : nullptr;
+          chain_posterior<T::NFB, T::NPB>(acc, prm, wf, e.x + (size_t)(p0 + wp) * e.D + fw, e.D, P - wp, F - fw, cA, cB, cC, t, zrow, e.ldzz,
+                                          e.seed, e.row_offset + (uint32_t)(p0 + wp), fw,
+                                          e.mut_mask ? e.mut_mask + (size_t)(p0 + wp) * e.mutation_dim : nullptr, e.mutation_dim, xp, lane);
         }
         if (CHAIN_EPI_PRIO) __builtin_amdgcn_s_setprio(0);
-        unsigned long long tt3 = 0;
+        unsigned long long tt3 = 0, te1 = 0, te2 = 0, te3 = 0, te4 = 0;
+        if constexpr (STAMP) te1 = __builtin_amdgcn_s_memtime();
         if (same_layer) {
           // same input panel, not touched by this epilogue: its first K stage goes out behind the stores, ONE wait covers both
-          first_stage(a.L[ln_next], f0_next, false, true);
+          first_stage(a.L[ln_next], f0_next, false, true, 0);
           if constexpr (STAMP) tt3 = __builtin_amdgcn_s_memtime();
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if constexpr (STAMP) te2 = __builtin_amdgcn_s_memtime();
           __syncthreads();
+          if constexpr (STAMP) te3 = te4 = __builtin_amdgcn_s_memtime();
         } else {
           // layer boundary (or the unit's last tile): every wave's stores have left before any wave stages the next layer's
           // input, which is this output
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if constexpr (STAMP) te2 = __builtin_amdgcn_s_memtime();
           __syncthreads();
-          if constexpr (STAMP) tt3 = __builtin_amdgcn_s_memtime();
+          if constexpr (STAMP) tt3 = te3 = __builtin_amdgcn_s_memtime();
           if (has_next) {
-            first_stage(a.L[ln_next], 0, false, true);
+            first_stage(a.L[ln_next], 0, false, true, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
           }
+          if constexpr (STAMP) te4 = __builtin_amdgcn_s_memtime();
         }
         if constexpr (STAMP) {
           c_pro += tt1 - tt0; c_k += tt2 - tt1; c_epi += tt3 - tt2;
           tt0 = tt3;
+          if (tid == 0) {
+            unsigned long long* kc = kcnt + 10 * L.kind;
+            kc[0] += tt2 - tt1; kc[1] += te1 - tt2; kc[2] += te2 - te1; kc[3] += te3 - te2; kc[4] += te4 - te3; kc[5] += 1;
+            if (ets[0]) { kc[6] += ets[0] - tt2; kc[7] += ets[1] - ets[0]; kc[8] += ets[2] - ets[1]; kc[9] += te1 - ets[2]; }
+          }
         }
       }
     }
@@ -518,10 +686,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
     }
   }
   if (STAMP && a.stamps && tid == 0) {
-    unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+    unsigned long long* o = a.stamps + (size_t)blockIdx.x * 64;
     o[0] = c_dep; o[1] = c_pro; o[2] = c_k; o[3] = c_epi; o[4] = __builtin_amdgcn_s_memtime() - c_start; o[5] = c_units;
     o[6] = __builtin_amdgcn_s_getreg(0xF804);      // HW_REG_HW_ID: where this workgroup ran
     o[7] = __builtin_amdgcn_s_getreg(0xF814) & 7;  // HW_REG_XCC_ID
+    for (int i = 0; i < 40; ++i) o[8 + i] = kcnt[i];
   }
 }
 

@@ -19,8 +19,11 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
   constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-    const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+    // one 32 x 32 -> 64 multiply per word (v_mad_u64_u32) instead of a mul_hi / mul_lo pair: integer multiplies are quarter-rate
+    // VALU work, and VALU cycles come straight out of the fp32 matrix loop's time (tools/probes/valu_mfma.hip)
+    const uint64_t p0 = (uint64_t)M0 * c.x, p1 = (uint64_t)M1 * c.z;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
     k.x += W0;
     k.y += W1;
@@ -40,8 +43,10 @@ __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 5.96
 // 4 standard normals from one Philox block (two Box-Muller pairs).
 // v_sin_f32 / v_cos_f32 take their argument in revolutions, so sin(2*pi*u) is one op.
 __device__ __forceinline__ float4 normal4(uint4 r) {
-  const float r0 = sqrtf(-2.0f * __logf(u01_open(r.x)));
-  const float r1 = sqrtf(-2.0f * __logf(u01_open(r.z)));
+  // radius = sqrt(-2 ln u) = sqrt(-2 ln2 * log2 u): v_log_f32, one multiply, v_sqrt_f32 (1 ulp; sqrtf() would add a
+  // ten-instruction correction sequence that buys nothing for a random draw)
+  const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01_open(r.x)));
+  const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01_open(r.z)));
   const float a0 = u01(r.y), a1 = u01(r.w);
   return make_float4(r0 * __builtin_amdgcn_cosf(a0), r0 * __builtin_amdgcn_sinf(a0),
                      r1 * __builtin_amdgcn_cosf(a1), r1 * __builtin_amdgcn_sinf(a1));

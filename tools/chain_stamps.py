@@ -15,20 +15,31 @@ m = BiologyAwareDiffusionModel(50, 1900, 50, 3, conf).cuda().eval()
 m.sampler, m.chain_stagger = "chain", stagger
 eng = m._engine()
 fn = L.lib().osd_dbg_chain_stamps; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p]
-buf = torch.zeros(1024 * 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(1024 * 64, dtype=torch.int64, device="cuda")
 cond = scenario_conditions(n, 0).cuda()
 m.sample(cond, n, seed=1)                       # warm-up, unstamped
 L.check(fn(eng.handle, L.ptr(buf)))
 torch.cuda.synchronize(); import time; t0 = time.perf_counter()
 m.sample(cond, n, seed=2)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-s = buf.cpu().numpy().reshape(-1, 8); s = s[s[:, 5] > 0]
+s = buf.cpu().numpy().reshape(-1, 64); s = s[s[:, 5] > 0]
 tot = s[:, 4].astype(float)
 print(f"n={n} T={steps} stagger={stagger}: {dt*1e3:.1f} ms, {n/dt*steps/1000:.0f} patient-ksteps/s, {len(s)} workgroups, units/wg {s[:,5].min()}..{s[:,5].max()}")
 for name, col in (("dependency wait", 0), ("tile prologue (first DMA stage)", 1), ("K loop", 2), ("epilogue + drain", 3)):
     sh = s[:, col] / tot
     print(f"  {name:34s} {100*sh.mean():6.2f} %  (min {100*sh.min():.2f}, max {100*sh.max():.2f})   {s[:, col].mean()/s[:,5].mean():12.0f} cycles/unit")
 print(f"  kernel cycles / unit {tot.mean()/s[:,5].mean():.0f}; clock ~ {tot.mean()/dt/1e9:.2f} GHz")
+
+# per layer kind: cycles per tile in each phase (workgroup mean)
+print("  per tile, by epilogue kind:   K loop | epilogue to last store issued | store drain | barrier | boundary first stage | tiles/unit")
+for kind, name in enumerate(("input_proj", "GroupNorm 32", "GroupNorm 64", "posterior")):
+    c = s[:, 8 + 10 * kind: 18 + 10 * kind].astype(float).sum(axis=0)
+    if c[5] == 0:
+        continue
+    print(f"    {name:14s}" + "".join(f"{c[i] / c[5]:10.0f}" for i in range(5)) + f"   {c[5] / s[:, 5].sum():6.1f}")
+    if c[6]:
+        print("        GroupNorm epilogue: first-stage A issue + bias loads landed | statistics | gamma/beta landed | normalise + SiLU + stores issued:"
+              + "".join(f"{c[i] / c[5]:9.0f}" for i in range(6, 10)))
 
 # placement: units completed per CU (both workgroups) and per XCD
 import collections
