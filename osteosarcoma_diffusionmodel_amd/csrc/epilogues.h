@@ -348,7 +348,7 @@ struct EpiGnBwd {
             const int r = 4 * q + e;
             const float zhat = (zv[e] - st.x) * st.y;
             const float y = zhat * gm[e] + bt[e];
-            const float sg = 1.0f / (1.0f + expf(-y));
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.4426950408889634f));   // hardware exp2 / rcp, as silu_f
             const float gyv = (acc[fb][pb][r] + av[e]) * keep[e] * (sg * (1.0f + y * (1.0f - sg)));
             const float gzh = gyv * gm[e];
             zh[fb][r] = zhat;

@@ -282,21 +282,35 @@ hipError_t launch_slab_reduce(hipStream_t s, const float* slabs, int ns, int row
 // ---- wgrad of a Linear with very few inputs (the condition MLP, cond_dim ~ 3):
 // dW[n][k] = sum_m gz[m][n] * x[m][k], one thread per (n,k), rows split over blocks, atomics at the end
 // dw and dbias (optional: the threads of column k == 0 also carry sum_m gz[m][n]) are ADDED to: zeroed by the caller
-__global__ void k_small_wgrad(const float* x, int kin, const float* gz, int ldg, int nout, int64_t rows, int rows_per_block, float* dw, float* dbias) {
-  const int i = threadIdx.x;
-  if (i >= nout * kin) return;
-  const int n = i / kin, k = i - n * kin;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  int64_t r1 = r0 + rows_per_block;
+__global__ __launch_bounds__(1024) void k_small_wgrad(const float* x, int kin, const float* gz, int ldg, int nout, int64_t rows, int rows_per_block, float* dw, float* dbias) {
+  // thread = (output i = n * kin + k, row group rg of 4): a block covers rows_per_block rows, each group a quarter of them; the
+  // groups meet in LDS so that a block issues ONE atomic per output (the atomics on 192 addresses serialise in L2: with one
+  // block per 64 rows they, not the loads, set the kernel's 20 us)
+  __shared__ float part[3][256], partb[3][256];
+  const int i = threadIdx.x & 255, rg = threadIdx.x >> 8;
+  const bool live = i < nout * kin;
+  const int n = live ? i / kin : 0, k = live ? i - n * kin : 0;
+  const int per = rows_per_block / 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block + (int64_t)rg * per;
+  int64_t r1 = r0 + per;
   if (r1 > rows) r1 = rows;
   float s = 0.f, sb = 0.f;
-  for (int64_t r = r0; r < r1; ++r) { const float g = gz[r * ldg + n]; s += g * x[r * kin + k]; sb += g; }
-  atomicAdd(dw + i, s);
-  if (dbias && k == 0) atomicAdd(dbias + n, sb);
+  if (live) {
+#pragma unroll 8
+    for (int64_t r = r0; r < r1; ++r) { const float g = gz[r * ldg + n]; s += g * x[r * kin + k]; sb += g; }
+  }
+  if (rg > 0) { part[rg - 1][i] = s; partb[rg - 1][i] = sb; }
+  __syncthreads();
+  if (rg == 0 && live) {
+    s += part[0][i] + part[1][i] + part[2][i];
+    sb += partb[0][i] + partb[1][i] + partb[2][i];
+    atomicAdd(dw + i, s);
+    if (dbias && k == 0) atomicAdd(dbias + n, sb);
+  }
 }
 hipError_t launch_small_wgrad(hipStream_t s, const float* x, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, float* dbias) {
   if (rows <= 0) return hipSuccess;
-  if (nout * kin > 1024) return hipErrorInvalidValue;
+  if (nout * kin > 256) return hipErrorInvalidValue;
   const int rpb = 64;
   hipLaunchKernelGGL(k_small_wgrad, (unsigned)((rows + rpb - 1) / rpb), 1024, 0, s, x, kin, gz, ldg, nout, rows, rpb, dw, dbias);
   return hipGetLastError();

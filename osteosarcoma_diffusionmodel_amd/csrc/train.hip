@@ -65,7 +65,7 @@ static int64_t carve_train(const Arch& a, float* base, int64_t n, const ConsPlan
 // dW[n_out][k_in] = sum_m gz[m][n_out] * x[m][k_in].  The reduction runs over the batch, the output is only
 // n_out x k_in: split the batch over blockIdx.y so that ~1024 workgroups exist, each writing its partial
 // tile to a slab, then sum the slabs in a fixed order (deterministic; no float atomics).
-static bool small_wgrad_ok(int kin, int nout, int lddw) { return kin <= 8 && nout * kin <= 1024 && lddw == kin; }
+static bool small_wgrad_ok(int kin, int nout, int lddw) { return kin <= 8 && nout * kin <= 256 && lddw == kin; }
 
 // `dbias_small`: taken by the small path only (it adds sum_m gz[m][n] into it); every other path leaves the bias to the caller
 static hipError_t wgrad(hipStream_t s, const TrainWs& w, const float* x, int ldx, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, int lddw,
@@ -139,6 +139,17 @@ static void add_backward_zeros(const Arch& a, const TrainWs& w, float* const* gr
 }
 
 
+// the handle's low-priority side stream (weight-gradient leaves of the backward pass, the conditioning branch of the forward)
+static int side_stream(osd_handle* h, hipStream_t* out) {
+  if (!h->wgrad_stream) {
+    int lo = 0, hi = 0;
+    OSD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    OSD_HIP(hipStreamCreateWithPriority(&h->wgrad_stream, hipStreamNonBlocking, lo));
+  }
+  *out = h->wgrad_stream;
+  return OSD_OK;
+}
+
 // The backward pass from dL/d eps_hat (d_out [n][D]) to every parameter gradient (and optionally dL/dx_t), over the
 // activations a training-mode forward left in W.
 static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* x_t, const int* t_idx, const float* cond, int64_t n,
@@ -156,14 +167,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   // lower-priority side stream that fills the CUs the small dgrad launches leave idle.  fork() orders the side
   // stream behind what the main stream has produced so far; the side stream owns the slab workspace.
   hipStream_t s2 = s;
-  if (h->two_stream_bwd) {
-    if (!h->wgrad_stream) {
-      int lo = 0, hi = 0;
-      OSD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      OSD_HIP(hipStreamCreateWithPriority(&h->wgrad_stream, hipStreamNonBlocking, lo));
-    }
-    s2 = h->wgrad_stream;
-  }
+  if (h->two_stream_bwd) OSD_TRY(side_stream(h, &s2));
   size_t ev_used = 0;
   auto next_event = [&](hipEvent_t* out) -> int {
     if (ev_used == h->ev_pool.size()) {
@@ -202,7 +206,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     const WgPending wp{x, ldx, kin, gz, ldg, nout, rows, dw, lddw, {b0, b1, b2}};
     if (grp && kin >= 16 && wgrad_group_ok(wp)) { pend.push_back(wp); return OSD_OK; }
     const bool small = small_wgrad_ok(kin, nout, lddw);
-    if (small && !events) {            // a 20 us kernel whose inputs are on the main stream: run it there, beside the side stream's GEMM
+    if (small && !events) {            // a 5 us kernel whose inputs are on the main stream: run it there (no fork, no event)
       OSD_HIP(wgrad(s, W, x, ldx, kin, gz, ldg, nout, rows, dw, lddw, b0));
       return OSD_OK;
     }
@@ -215,17 +219,19 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
         if (bx) OSD_HIP(hipMemcpyAsync(bx, b0, (size_t)nout * 4, hipMemcpyDeviceToDevice, s2));
     return OSD_OK;
   };
-  auto flush = [&](bool leave_room) -> int {
+  // mid-pass flush (data parallel: the decoder half's buckets can go to the wire early): grouped weight gradients on the side
+  // stream, one workgroup per CU walking the list so that the other slot of every CU stays with the dgrad chain of the main
+  // stream (a full-width launch starved it: a 16 us dgrad took 104 us)
+  hipEvent_t mid_done = nullptr;       // the side stream is through with the slab workspace
+  auto flush_mid = [&]() -> int {
     if (!grp) return OSD_OK;
     OSD_TRY(fork());                  // the side stream sees every gz produced so far
-    // mid-pass flush: one workgroup per CU walks the list, the other slot of every CU stays with the dgrad chain of the
-    // main stream (a full-width launch starved it: a 16 us dgrad took 104 us); the final flush has the GPU to itself
     static const int mid_cap = [] { const char* e = getenv("OSD_WGRAD_MID_CAP"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
-    const int cap = (leave_room && s2 != s) ? mid_cap : 0;
-    OSD_TRY(wgrad_group_flush(h, s2, n_flush++, pend, W.slabs, W.slab_floats, cap));
+    OSD_TRY(wgrad_group_flush(h, s2, n_flush++, pend, W.slabs, W.slab_floats, s2 != s ? mid_cap : 0));
     pend.clear();
     for (; ev < ev_closed; ++ev)
       if (events) OSD_HIP(hipEventRecord((hipEvent_t)events[ev], s2));
+    if (s2 != s) { OSD_TRY(next_event(&mid_done)); OSD_HIP(hipEventRecord(mid_done, s2)); }
     return OSD_OK;
   };
   // GroupNorm backward: inside the epilogue of the dgrad that produces the layer's upstream gradient (group widths 32 / 64), or
@@ -235,16 +241,46 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   for (const LayerDesc& l : a.layers) fuse = fuse && dgrad_gnbwd_supported(l.gw);
   const float keep_scale = (float)(1.0 / (1.0 - (double)h->cfg.dropout_p));
   std::vector<GnColItem> cols;
-  auto flush_all = [&](bool leave_room) -> int {
+  // d gamma / d beta of the layers whose backward ran in a dgrad epilogue: memory-bound leaves, one launch per call.  They
+  // go to the side stream as soon as the block loop is through (beside the last small GEMMs of the main stream), not next to
+  // the grouped weight-gradient launch, whose 512 workgroups would keep them off the CUs until it ends.
+  int n_cols_flush = 0;
+  auto side_leaves = [&](hipStream_t st) -> int {
     if (!cols.empty()) {
-      // d gamma / d beta of the layers whose backward ran in a dgrad epilogue.  Data parallel (bucket events): on the side
-      // stream AHEAD of the weight gradients, so that the events flush() records behind those cover them too.  Otherwise on
-      // the main stream, where gy / z were produced (no fork) and the memory-bound sums overlap the side stream's GEMM.
-      if (events && s2 != s) { OSD_TRY(fork()); OSD_TRY(gn_colsums_flush(h, s2, n_flush + 8, cols)); }
-      else OSD_TRY(gn_colsums_flush(h, s, n_flush + 8, cols));      // plan slots 8.. hold the column-sum lists
+      OSD_TRY(gn_colsums_flush(h, st, 8 + n_cols_flush++, cols));      // plan slots 8.. hold the column-sum lists
       cols.clear();
     }
-    return flush(leave_room);
+    return OSD_OK;
+  };
+  auto flush_all = [&](bool mid) -> int {
+    if (mid) {
+      // the events flush_mid() records behind the weight gradients must cover the affine gradients too: those go first
+      if (s2 != s && !cols.empty()) OSD_TRY(fork());
+      OSD_TRY(side_leaves(s2));
+      return flush_mid();
+    }
+    // End of the pass.  The grouped weight-gradient GEMM (the long pole, ~200 us at batch 4096) stays on the MAIN stream: no
+    // stream hop in front of it or between it and the optimizer.  The memory-bound leaves run beside it on the side stream and
+    // are long done when the main stream joins.
+    if (s2 != s) {
+      if (!cols.empty()) { OSD_TRY(fork()); OSD_TRY(side_leaves(s2)); }
+      if (mid_done) OSD_HIP(hipStreamWaitEvent(s, mid_done, 0));     // slab workspace handed back by the mid-pass flush
+    } else {
+      OSD_TRY(side_leaves(s));
+    }
+    if (grp) {
+      OSD_TRY(wgrad_group_flush(h, s, n_flush++, pend, W.slabs, W.slab_floats, 0));
+      pend.clear();
+    }
+    if (s2 != s) {
+      hipEvent_t e;
+      OSD_TRY(next_event(&e));
+      OSD_HIP(hipEventRecord(e, s2));
+      OSD_HIP(hipStreamWaitEvent(s, e, 0));
+    }
+    for (; ev < ev_closed; ++ev)
+      if (events) OSD_HIP(hipEventRecord((hipEvent_t)events[ev], s));
+    return OSD_OK;
   };
   // dgrad whose epilogue is the GroupNorm+SiLU(+dropout) backward of `ln` (z / stats of that layer): writes dL/dz and dL/dy
   auto dgrad_fused = [&](const float* w, int ldw, int kin, const float* gz_next, int ldg, int nout, const LayerDesc& ln, const float* z,
@@ -324,6 +360,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     OSD_HIP(dgrad(s, h->params[l1.w], Kt, l1.K1, W.g_z1[b], C, C, n, gdst, l1.K1, acc));
     if (l1.K2 > 0) OSD_HIP(dgrad(s, h->params[l1.w] + l1.K1, Kt, l1.K2, W.g_z1[b], C, C, n, W.g_out[skip_block], l1.K2, false));
   }
+  if (s2 != s && !cols.empty()) { OSD_TRY(fork()); OSD_TRY(side_leaves(s2)); }      // every GroupNorm layer's gy / z is final
   // input_proj, time_proj, cond_proj, ConditionalEmbedding  (h0 = x W^T + b + t_emb[t] + c_proj)
   if (dx_t) OSD_HIP(dgrad(s, h->params[pm.in_w], D, D, W.g_h0, a.H0, a.H0, n, dx_t, D, false));
   // h0 = x W^T + b_in + (t_emb W_t^T + b_t)[t] + (c W_c^T + b_c): the three biases share one gradient, the column sums of g_h0
@@ -338,13 +375,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   OSD_HIP(launch_silu_bwd(s, W.u0, W.g_ce1, W.g_u, n * 64));
   OSD_TRY(wg(cond, a.cond_dim, a.cond_dim, W.g_u, 64, 64, n, grads[pm.ce0_w], a.cond_dim, grads[pm.ce0_b]));
   OSD_TRY(record());
-  OSD_TRY(flush_all(false));
-  if (s2 != s) {                      // join: the caller's stream owns every result again
-    hipEvent_t e;
-    OSD_TRY(next_event(&e));
-    OSD_HIP(hipEventRecord(e, s2));
-    OSD_HIP(hipStreamWaitEvent(s, e, 0));
-  }
+  OSD_TRY(flush_all(false));          // ends with the side stream joined: the caller's stream owns every result again
   return OSD_OK;
 }
 
