@@ -1,13 +1,13 @@
 // validate.hip -- on-GPU validation metrics (utils/validation.py): RBF-MMD as a
 // blocked Gram GEMM with an exp+reduce epilogue, per-feature two-sample Kolmogorov-Smirnov extremes over
-// hipCUB segmented sorts, within-pathway mean correlation and Pearson correlation as wavefront reductions.
+// a hand-written segmented radix sort (segsort.h), within-pathway mean correlation and Pearson correlation as wavefront reductions.
 // Entry points are stream/device based (no model handle) and synchronous: they return host scalars.
-#include <hipcub/hipcub.hpp>
 #include <limits.h>
 #include <vector>
 #include "handle.h"
 #include "kernels.h"
 #include "launch.h"
+#include "segsort.h"
 
 namespace osd {
 
@@ -195,7 +195,7 @@ int osd_val_ks_extremes(void* stream, int device, const float* real, int64_t n1,
   if ((double)n1 * nf > 2.0e9 || (double)n2 * nf > 2.0e9) { set_error("too many items for one segmented sort"); return OSD_EINVAL; }
   OSD_HIP(hipSetDevice(device));
   hipStream_t s = (hipStream_t)stream;
-  DevBuf cols, sorted, offs, ext, tmp;
+  DevBuf cols, sorted, ext, tmp;
   const size_t na = (size_t)n1 * nf, nb = (size_t)n2 * nf;
   OSD_HIP(cols.alloc((na + nb) * 4));
   OSD_HIP(sorted.alloc((na + nb) * 4));
@@ -204,17 +204,30 @@ int osd_val_ks_extremes(void* stream, int device, const float* real, int64_t n1,
   float* sa = (float*)sorted.p; float* sb = sa + na;
   hipLaunchKernelGGL(k_gather_cols, 2048, 256, 0, s, real, ld, n1, nf, ca);
   hipLaunchKernelGGL(k_gather_cols, 2048, 256, 0, s, synth, ld, n2, nf, cb);
-  std::vector<int> h_off((size_t)2 * (nf + 1));
-  for (int f = 0; f <= nf; ++f) { h_off[f] = (int)((int64_t)f * n1); h_off[nf + 1 + f] = (int)((int64_t)f * n2); }
-  OSD_HIP(offs.alloc(h_off.size() * sizeof(int)));
-  OSD_HIP(hipMemcpyAsync(offs.p, h_off.data(), h_off.size() * sizeof(int), hipMemcpyHostToDevice, s));
-  int* oa = (int*)offs.p; int* ob = oa + nf + 1;
-  size_t bytes_a = 0, bytes_b = 0;
-  OSD_HIP(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes_a, ca, sa, (int)na, nf, oa, oa + 1, 0, 32, s));
-  OSD_HIP(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes_b, cb, sb, (int)nb, nf, ob, ob + 1, 0, 32, s));
-  OSD_HIP(tmp.alloc(bytes_a > bytes_b ? bytes_a : bytes_b));
-  OSD_HIP(hipcub::DeviceSegmentedRadixSort::SortKeys(tmp.p, bytes_a, ca, sa, (int)na, nf, oa, oa + 1, 0, 32, s));
-  OSD_HIP(hipcub::DeviceSegmentedRadixSort::SortKeys(tmp.p, bytes_b, cb, sb, (int)nb, nf, ob, ob + 1, 0, 32, s));
+  // four stable 8-bit passes, ping-pong between the two buffers: the sorted floats end up back in `cols`
+  {
+    const int wps_a = (int)((n1 + SEG_CHUNK - 1) / SEG_CHUNK), wps_b = (int)((n2 + SEG_CHUNK - 1) / SEG_CHUNK);
+    OSD_HIP(tmp.alloc((size_t)nf * 256 * (size_t)(wps_a > wps_b ? wps_a : wps_b) * sizeof(int)));
+    int* cnt = (int*)tmp.p;
+    auto sort_segments = [&](float* buf0, float* buf1, long long n, int wps) -> hipError_t {
+      uint32_t* a = (uint32_t*)buf0; uint32_t* b = (uint32_t*)buf1;
+      const dim3 grid((unsigned)((wps + SEG_WAVES - 1) / SEG_WAVES), (unsigned)nf), block(64 * SEG_WAVES);
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 8 * pass;
+        if (pass == 0) hipLaunchKernelGGL((k_seg_count<true>), grid, block, 0, s, a, n, wps, shift, cnt);
+        else hipLaunchKernelGGL((k_seg_count<false>), grid, block, 0, s, a, n, wps, shift, cnt);
+        hipLaunchKernelGGL(k_seg_scan, dim3((unsigned)nf), dim3(256), 0, s, cnt, wps);
+        if (pass == 0) hipLaunchKernelGGL((k_seg_scatter<true, false>), grid, block, 0, s, a, b, n, wps, shift, cnt);
+        else if (pass == 3) hipLaunchKernelGGL((k_seg_scatter<false, true>), grid, block, 0, s, a, b, n, wps, shift, cnt);
+        else hipLaunchKernelGGL((k_seg_scatter<false, false>), grid, block, 0, s, a, b, n, wps, shift, cnt);
+        uint32_t* t = a; a = b; b = t;
+      }
+      return hipGetLastError();
+    };
+    OSD_HIP(sort_segments(ca, sa, (long long)n1, wps_a));
+    OSD_HIP(sort_segments(cb, sb, (long long)n2, wps_b));
+    sa = ca; sb = cb;                     // an even number of passes: back in the first buffer
+  }
   std::vector<long long> init((size_t)2 * nf);
   for (int f = 0; f < nf; ++f) { init[f] = LLONG_MIN; init[nf + f] = LLONG_MAX; }
   long long* emax = (long long*)ext.p; long long* emin = emax + nf;

@@ -71,6 +71,28 @@ def test_metrics_at_scale_vs_oracle():
         val._mean_offdiag(x, [0])
 
 
+def test_ks_sort_edge_values():
+    """The segmented radix sort under the KS statistic (csrc/segsort.h): segments shorter than one wave step, lengths that
+    are not multiples of the 4096-key chunk, +-0, denormal-sized and huge magnitudes, 0/1 columns (all ties), constant
+    columns.  The statistic is an exact integer function of the two sorted samples: any misplaced key changes it."""
+    rs = np.random.RandomState(11)
+    for n1, n2 in ((37, 50), (4096, 4097), (8191, 63)):
+        D = 8
+        real = rs.randn(n1, D).astype(np.float32)
+        synth = rs.randn(n2, D).astype(np.float32)
+        real[:, 0] = (rs.rand(n1) < 0.3); synth[:, 0] = (rs.rand(n2) < 0.4)                       # mutation-like
+        real[:, 1] *= 1e30; synth[:, 1] *= 1e-30                                                   # exponent extremes
+        real[:, 2] = np.where(rs.rand(n1) < 0.5, 0.0, -0.0); synth[:, 2] = np.where(rs.rand(n2) < 0.5, -0.0, 0.0)
+        real[:, 3] = 2.5; synth[:, 3] = 2.5                                                         # constant
+        real[:, 4] = -np.abs(real[:, 4]); synth[:, 4] = np.abs(synth[:, 4])                         # disjoint supports
+        val = BiologicalValidator(CONF)
+        d, p = val.ks_tests(real, synth, max_features=D)
+        for i in range(D):
+            dmax, dmin = V.ks_count_extremes(real[:, i], synth[:, i])
+            dd, pp = V.ks_pvalue(n1, n2, dmax, dmin)
+            assert d[i] == dd and p[i] == pp, (n1, n2, i)
+
+
 REF_EVAL = {"evaluation": {"driver_genes": ["TP53", "RB1", "ATRX", "DLG2", "PTEN"], "mutually_exclusive_pairs": [["TP53", "MDM2"]],
                            "required_correlations": [{"mutation": "TP53", "pathway": "HALLMARK_P53_PATHWAY", "direction": "negative"},
                                                      {"mutation": "MYC", "pathway": "HALLMARK_MYC_TARGETS_V1", "direction": "positive"}]}}
