@@ -107,6 +107,11 @@ __device__ __forceinline__ bool chain_wait(const unsigned* word, unsigned want, 
 // WaveXpose: [32 * NPB rows][32 floats], 16-byte chunks XOR-swizzled by (row & 7): conflict-free for both access patterns.
 // LDS instructions of one wave execute in order, so a block's reads follow its writes (and the next block's writes follow these
 // reads) without any barrier; the compiler keeps the order because the accesses may alias.
+// The chain kernel's argument block lives in memory, so every pointer loaded from it is a GENERIC pointer to hipcc and an
+// access through it becomes a FLAT instruction (both counters, out-of-order return: every wait degrades to vmcnt(0) &
+// lgkmcnt(0), and the LDS pipe is involved in a global access).  The epilogues therefore go through the explicitly global
+// accessors ldg4 / stg4 / stg1 of gemm_glds.h (same box: 22.42 k -> 22.80 k patients/s).
+
 template <int NPB>
 struct WaveXpose {
   float* buf;
@@ -127,7 +132,7 @@ struct WaveXpose {
     for (int i = 0; i < 4 * NPB; ++i) {
       const int row = 8 * i + (lane >> 3);
       const float4 v = *reinterpret_cast<const float4*>(buf + row * 32 + 4 * (c ^ (row & 7)));
-      if (!GUARD || (row < rows && 4 * c < cols)) *reinterpret_cast<float4*>(g + (size_t)row * ld + 4 * c) = v;
+      if (!GUARD || (row < rows && 4 * c < cols)) stg4(g + (size_t)row * ld + 4 * c, v);
     }
   }
   // rows beyond `rows` / chunks beyond `cols` re-read the last valid ones (finite values that are never stored)
@@ -140,7 +145,7 @@ struct WaveXpose {
       int row = 8 * i + (lane >> 3);
       int cc = 4 * c;
       if (GUARD) { row = row < rows ? row : rows - 1; cc = cc < cols - 4 ? cc : cols - 4; }
-      v[i] = *reinterpret_cast<const float4*>(g + (size_t)row * ld + cc);
+      v[i] = ldg4(g + (size_t)row * ld + cc);
     }
 #pragma unroll
     for (int i = 0; i < 4 * NPB; ++i) {
@@ -257,18 +262,20 @@ __device__ __forceinline__ void chain_posterior(f32x16 (&acc)[NFB][NPB], const f
                                                 uint64_t seed, uint32_t row_id0, int f_glob, float* __restrict__ mut_mask, int mutation_dim,
                                                 const WaveXpose<NPB>& xp, int lane) {
   const int l31 = lane & 31, h = lane >> 5;
+  constexpr bool GUARD = true;                // a guard-free variant for full blocks was measured: +0.3 % (noise), 4 spills, +14 KB of code
   if (prow <= 0) return;                      // uniform over the wave
+  const bool do_mask = t == 0 && mut_mask != nullptr;      // uniform
 #pragma unroll
   for (int fb = 0; fb < NFB; ++fb) {
     const int cols = pcol - 32 * fb;          // valid features of this block
-    if (cols <= 0) break;                     // uniform
+    if (GUARD && cols <= 0) break;            // uniform
     // x_t of the block in row segments; a lane then reads and rewrites only its own fragment slots, so each get() can sit
     // right before its use (no 32-register copy of the block)
-    xp.template load_rows<true>(x + 32 * fb, ldx, lane, prow, cols);
+    xp.template load_rows<GUARD>(x + 32 * fb, ldx, lane, prow, cols);
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) {
       const int p = 32 * pb + l31;            // row inside the wave's rows
-      const int pc = p < prow ? p : prow - 1;
+      const int pc = (!GUARD || p < prow) ? p : prow - 1;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int fo = 32 * fb + 8 * q + 4 * h;           // feature offset from the wave's first
@@ -279,8 +286,8 @@ __device__ __forceinline__ void chain_posterior(f32x16 (&acc)[NFB][NPB], const f
         float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t > 0) {
           if (zrow) {
-            const int fc = fo < pcol - 4 ? fo : pcol - 4;
-            zz = *reinterpret_cast<const float4*>(zrow + (size_t)pc * ldzz + fc);
+            const int fc = (!GUARD || fo < pcol - 4) ? fo : pcol - 4;
+            zz = ldg4(zrow + (size_t)pc * ldzz + fc);
           } else {
             zz = randn4(seed, row_id0 + (uint32_t)p, (uint32_t)((f_glob + fo) >> 2), (uint32_t)t, TAG_POSTERIOR);
           }
@@ -289,16 +296,16 @@ __device__ __forceinline__ void chain_posterior(f32x16 (&acc)[NFB][NPB], const f
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = fmaf(cA, xv[r], fmaf(cB, e[r], cC * zv[r]));
-        if (t == 0 && mut_mask && p < prow && fo < pcol && f_glob + fo < mutation_dim) {
+        if (do_mask && p < prow && fo < pcol && f_glob + fo < mutation_dim) {
           float* mrow = mut_mask + (size_t)p * mutation_dim;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (f_glob + fo + r < mutation_dim) mrow[f_glob + fo + r] = (o[r] > 0.5f) ? 1.0f : 0.0f;
+            if (f_glob + fo + r < mutation_dim) stg1(mrow + f_glob + fo + r, (o[r] > 0.5f) ? 1.0f : 0.0f);
         }
         xp.put(pb, q, l31, h, make_float4(o[0], o[1], o[2], o[3]));
       }
     }
-    xp.template store_rows<true>(x + 32 * fb, ldx, lane, prow, cols);
+    xp.template store_rows<GUARD>(x + 32 * fb, ldx, lane, prow, cols);
   }
 }
 
@@ -637,9 +644,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
           const float* c = e.coef + 4 * t;
           const float cA = c[0], cB = c[1], cC = c[2];
           const float* zrow = e.z ? e.z + (long long)(e.z_t_first - t) * e.z_step_stride + (size_t)(p0 + wp) * e.ldzz + fw : nullptr;
+          float* const mm = e.mut_mask ? e.mut_mask + (size_t)(p0 + wp) * e.mutation_dim : nullptr;
           chain_posterior<T::NFB, T::NPB>(acc, prm, wf, e.x + (size_t)(p0 + wp) * e.D + fw, e.D, P - wp, F - fw, cA, cB, cC, t, zrow, e.ldzz,
-                                          e.seed, e.row_offset + (uint32_t)(p0 + wp), fw,
-                                          e.mut_mask ? e.mut_mask + (size_t)(p0 + wp) * e.mutation_dim : nullptr, e.mutation_dim, xp, lane);
+                                          e.seed, e.row_offset + (uint32_t)(p0 + wp), fw, mm, e.mutation_dim, xp, lane);
         }
         if (CHAIN_EPI_PRIO) __builtin_amdgcn_s_setprio(0);
         unsigned long long tt3 = 0, te1 = 0, te2 = 0, te3 = 0, te4 = 0;

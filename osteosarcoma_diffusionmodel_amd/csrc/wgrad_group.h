@@ -134,8 +134,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_group_kernel(const WgItem* 
         const int f = it.f0 + wf + 32 * fb + 8 * q + 4 * h;
         const int p = it.p0 + wp + 32 * pb + l31;
         if (p < it.P && f < it.F)
-          *reinterpret_cast<float4*>(it.out + (size_t)p * it.ldo + f) =
-              make_float4(acc[fb][pb][4 * q], acc[fb][pb][4 * q + 1], acc[fb][pb][4 * q + 2], acc[fb][pb][4 * q + 3]);
+          stg4(it.out + (size_t)p * it.ldo + f, make_float4(acc[fb][pb][4 * q], acc[fb][pb][4 * q + 1], acc[fb][pb][4 * q + 2], acc[fb][pb][4 * q + 3]));
       }
   __syncthreads();                          // the next item restages buffer 0
   }

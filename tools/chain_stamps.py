@@ -13,6 +13,7 @@ conf = {"model": dict(CONF["model"])}; conf["model"]["diffusion"] = {"num_steps"
 torch.manual_seed(0)
 m = BiologyAwareDiffusionModel(50, 1900, 50, 3, conf).cuda().eval()
 m.sampler, m.chain_stagger = "chain", stagger
+if len(sys.argv) > 4: m.chain_grid = int(sys.argv[4])
 eng = m._engine()
 fn = L.lib().osd_dbg_chain_stamps; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p]
 buf = torch.zeros(1024 * 64, dtype=torch.int64, device="cuda")
