@@ -25,6 +25,7 @@
 #pragma once
 #include "gemm_glds.h"
 #include "epilogues.h"
+#include "xpose.h"
 #include "launch.h"
 
 namespace osd {
@@ -96,67 +97,8 @@ __device__ __forceinline__ bool chain_wait(const unsigned* word, unsigned want, 
   }
 }
 
-// ---- epilogue plumbing of the chain kernel --------------------------------------------------------------------------------
-// The MFMA fragment layout (gemm.h) gives a lane ONE row and 4 consecutive features per register quad, so a float4 store
-// straight from the accumulators touches 32 rows x 32 bytes: a quarter of a 128-byte line per row, 32 L2 write transactions per
-// wave-instruction, and the other three quarters of each line arrive with later instructions.  In-kernel stamps put 22 000 of a
-// GroupNorm tile's 31 000 epilogue cycles into issuing those 16 stores (the statistics take 600).  The chain kernel therefore
-// turns every 32-feature block through LDS -- the K loop's second operand buffer is idle during an epilogue, 8 KB per wave --
-// and stores (and loads x_t / cond_proj) as full 128-byte row segments, 8 rows per wave-instruction.
-//
-// WaveXpose: [32 * NPB rows][32 floats], 16-byte chunks XOR-swizzled by (row ^ (row >> 3)) & 7.  A plain row & 7 serves the
-// 8-lane groups of ds_write_b128 and the row-side reads, but ds_read_b128 is banked over the lane groups
-// {0-3, 12-15, 20-27}, ..., where rows 0 and 24 (or 2 and 26, ...) share row & 7 and parity: 2-way conflicts (PMC: 0.14 % of
-// the kernel's cycles).  Folding row >> 3 in makes the fragment-side read, the row-side read and both writes conflict-free.
-// LDS instructions of one wave execute in order, so a block's reads follow its writes (and the next block's writes follow these
-// reads) without any barrier; the compiler keeps the order because the accesses may alias.
-// The chain kernel's argument block lives in memory, so every pointer loaded from it is a GENERIC pointer to hipcc and an
-// access through it becomes a FLAT instruction (both counters, out-of-order return: every wait degrades to vmcnt(0) &
-// lgkmcnt(0), and the LDS pipe is involved in a global access).  The epilogues therefore go through the explicitly global
-// accessors ldg4 / stg4 / stg1 of gemm_glds.h (same box: 22.42 k -> 22.80 k patients/s).
-
-__device__ __forceinline__ int xsw(int row) { return (row ^ (row >> 3)) & 7; }
-template <int NPB>
-struct WaveXpose {
-  float* buf;
-  // fragment side: lane (l31, h) owns row 32 pb + l31, chunk 2 q + h of the block
-  // (xsw(32 pb + l31) = xsw(l31) ^ 4 pb: one lane constant, the rest folds into the unrolled pb / q)
-  __device__ __forceinline__ void put(int pb, int q, int l31, int h, float4 v) const {
-    const int sw = h ^ xsw(l31);
-    *reinterpret_cast<float4*>(buf + l31 * 32 + pb * 1024 + 4 * (sw ^ ((2 * q) ^ (4 * pb & 7)))) = v;
-  }
-  __device__ __forceinline__ float4 get(int pb, int q, int l31, int h) const {
-    const int sw = h ^ xsw(l31);
-    return *reinterpret_cast<const float4*>(buf + l31 * 32 + pb * 1024 + 4 * (sw ^ ((2 * q) ^ (4 * pb & 7))));
-  }
-  // row side: instruction i moves rows 8 i .. 8 i + 7, eight lanes per row (128 contiguous bytes)
-  template <bool GUARD>
-  __device__ __forceinline__ void store_rows(float* __restrict__ g, int ld, int lane, int rows, int cols) const {
-    const int c = lane & 7, r = lane >> 3, cr = c ^ r;      // xsw(8 i + r) = r ^ (i & 7)
-#pragma unroll
-    for (int i = 0; i < 4 * NPB; ++i) {
-      const int row = 8 * i + r;
-      const float4 v = *reinterpret_cast<const float4*>(buf + r * 32 + i * 256 + 4 * (cr ^ (i & 7)));
-      if (!GUARD || (row < rows && 4 * c < cols)) stg4(g + (size_t)row * ld + 4 * c, v);
-    }
-  }
-  // rows beyond `rows` / chunks beyond `cols` re-read the last valid ones (finite values that are never stored)
-  template <bool GUARD>
-  __device__ __forceinline__ void load_rows(const float* __restrict__ g, int ld, int lane, int rows, int cols) const {
-    const int c = lane & 7, r = lane >> 3, cr = c ^ r;
-    float4 v[4 * NPB];
-#pragma unroll
-    for (int i = 0; i < 4 * NPB; ++i) {
-      int row = 8 * i + r;
-      int cc = 4 * c;
-      if (GUARD) { row = row < rows ? row : rows - 1; cc = cc < cols - 4 ? cc : cols - 4; }
-      v[i] = ldg4(g + (size_t)row * ld + cc);
-    }
-#pragma unroll
-    for (int i = 0; i < 4 * NPB; ++i) *reinterpret_cast<float4*>(buf + r * 32 + i * 256 + 4 * (cr ^ (i & 7))) = v[i];
-  }
-};
-
+// ---- epilogue plumbing of the chain kernel: the LDS row transposer of xpose.h (outputs leave, and x_t / cond_proj arrive,
+// as full 128-byte row segments) and per-feature parameters staged in LDS --------------------------------------------------
 // Per-feature parameters of a tile in LDS: prm[0..127] bias, [128..255] gamma (input_proj: the time-embedding row), [256..383]
 // beta, for features f0 .. f0 + 127.  They arrive by DMA together with the tile's first weight stage (issued under the
 // previous tile's epilogue), so no epilogue waits for a parameter load from L2 (stamps: two round trips of ~4 500 cycles each).

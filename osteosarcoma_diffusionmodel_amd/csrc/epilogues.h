@@ -7,6 +7,7 @@
 #pragma once
 #include "gemm.h"
 #include "rng.h"
+#include "xpose.h"
 
 namespace osd {
 
@@ -40,6 +41,7 @@ struct NoSync {
 template <bool SILU, bool ACCUM>
 struct EpiBias {
   static constexpr bool COUNTED_STORES = true;    // one float4 store per accumulator quad on a full tile
+  static constexpr bool XBUF = false;             // true: apply() takes the wave's LDS transposer region (xpose.h)
   struct Args { const float* bias; float* out; int ldo; long long slice_stride; };
   static bool fast_ok(const Args& a, int F) { return F % 4 == 0 && al16(a.bias) && al16(a.out) && a.ldo % 4 == 0 && a.slice_stride % 4 == 0; }
   static __device__ __forceinline__ void slice(Args& a, int y) { a.out += (long long)y * a.slice_stride; }
@@ -77,6 +79,7 @@ struct EpiBias {
 // ---- input_proj: h = ((x W^T + b) + t_emb[t]) + c_proj   (models/diffusion.py:229-232) ----
 struct EpiInput {
   static constexpr bool COUNTED_STORES = true;
+  static constexpr bool XBUF = false;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias;
@@ -141,6 +144,7 @@ struct EpiInput {
 template <int GW, bool DROP>
 struct EpiGnSilu {
   static constexpr bool COUNTED_STORES = true;
+  static constexpr bool XBUF = false;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias; const float* gamma; const float* beta;
@@ -266,6 +270,7 @@ struct EpiGnSilu {
 template <int GW, bool DROP>
 struct EpiGnBwd {
   static constexpr bool COUNTED_STORES = false;
+  static constexpr bool XBUF = false;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* z; int ldz;          // pre-norm activations of layer L  [P][F]
@@ -399,6 +404,7 @@ struct EpiGnBwd {
 // differs from the reference's op order by a few ulp of the same intermediate magnitudes.
 struct EpiPosterior {
   static constexpr bool COUNTED_STORES = true;
+  static constexpr bool XBUF = false;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias;
@@ -487,6 +493,7 @@ struct EpiPosterior {
 // d = (acc + bias) - noise;  loss += sum d^2 * inv_count;  dout = d * gscale
 struct EpiMse {
   static constexpr bool COUNTED_STORES = false;   // dout / pred are optional
+  static constexpr bool XBUF = true;              // the noise target comes in, dL/d eps goes out, as full row segments
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args {
     const float* bias; const float* noise; int ldn;
@@ -510,11 +517,47 @@ struct EpiMse {
       for (int q = 0; q < 4; ++q) r.bias[fb][q] = ldq<FAST>(a.bias, fw + 32 * fb + 8 * q + 4 * h, F);
     return r;
   }
+  // xbuf (FAST only): the wave's transposer region; the 32-feature blocks of the noise target are read, and those of dL/d eps
+  // written, as full 128-byte row segments (xpose.h) instead of 32 rows x 32 bytes per wave-instruction
   template <int NFB, int NPB, bool FAST, class Sync = NoSync>
   static __device__ __forceinline__ void apply(f32x16 (&acc)[NFB][NPB], const Args& a, const Pre<NFB>& pre, int fw, int pw, int lane, int F, int P,
-                                               Sync&& sync = Sync()) {
+                                               float* xbuf = nullptr, Sync&& sync = Sync()) {
     const int l31 = lane & 31, h = lane >> 5;
     float part = 0.f;
+    if (FAST && xbuf) {
+      const WaveXpose<NPB> xp{xbuf};
+      const int rows = P - pw;                         // valid rows of the wave's block (uniform)
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) {
+        const int cols = F - (fw + 32 * fb);            // valid features of this block (uniform)
+        if (rows <= 0 || cols <= 0) continue;
+        xp.template load_rows<true>(a.noise + (size_t)pw * a.ldn + fw + 32 * fb, a.ldn, lane, rows, cols);
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int fo = 8 * q + 4 * h;
+            const int p = 32 * pb + l31;
+            const bool prow = p < rows;
+            const float4 bv = pre.bias[fb][q];
+            const float4 nz = xp.get(pb, q, l31, h);
+            const float4 e = make_float4(acc[fb][pb][4 * q] + bv.x, acc[fb][pb][4 * q + 1] + bv.y, acc[fb][pb][4 * q + 2] + bv.z, acc[fb][pb][4 * q + 3] + bv.w);
+            if (a.pred && prow) stq<FAST>(a.pred + (size_t)(pw + p) * a.ldp, fw + 32 * fb + fo, F, e);
+            float4 d = make_float4(e.x - nz.x, e.y - nz.y, e.z - nz.z, e.w - nz.w);
+            if (!prow || fo >= cols) d.x = 0.f;
+            if (!prow || fo + 1 >= cols) d.y = 0.f;
+            if (!prow || fo + 2 >= cols) d.z = 0.f;
+            if (!prow || fo + 3 >= cols) d.w = 0.f;
+            part += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+            xp.put(pb, q, l31, h, make_float4(d.x * a.gscale, d.y * a.gscale, d.z * a.gscale, d.w * a.gscale));
+          }
+        if (a.dout) xp.template store_rows<true>(a.dout + (size_t)pw * a.ldd + fw + 32 * fb, a.ldd, lane, rows, cols);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+      if (lane == 0) atomicAdd(a.loss, part * a.inv_count);
+      return;
+    }
     OSD_FOR_QUADS(fb, pb, q) {
       const int f = fw + 32 * fb + 8 * q + 4 * h;
       const int p = pw + 32 * pb + l31;
@@ -543,6 +586,7 @@ struct EpiMse {
 // acc = x_f . y_p;  d2 = |x_f|^2 + |y_p|^2 - 2 acc;  sum += exp(-gamma * max(d2, 0)) over the valid tile
 struct EpiRbfSum {
   static constexpr bool COUNTED_STORES = false;   // stores nothing
+  static constexpr bool XBUF = false;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
   struct Args { const float* sqa; const float* sqb; float gamma; double* sum; };
   static bool fast_ok(const Args& a, int F) { return F % 4 == 0 && al16(a.sqa); }

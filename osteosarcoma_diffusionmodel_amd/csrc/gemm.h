@@ -303,7 +303,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g, typename 
   }
 
   const auto pre = Epi::template prefetch<T::NFB, FAST>(ea, f0 + wf, lane, g.F);
-  Epi::template apply<T::NFB, T::NPB, FAST>(acc, ea, pre, f0 + wf, p0 + wp, lane, g.F, g.P);
+  if constexpr (Epi::XBUF) {
+    // every wave has left the K loop through its last barrier: the staging buffers are free for the epilogue's row transposer
+    static_assert(4 * T::NPB * 1024 * 4 <= T::LDS_BYTES, "transposer regions must fit the staging buffers");
+    Epi::template apply<T::NFB, T::NPB, FAST>(acc, ea, pre, f0 + wf, p0 + wp, lane, g.F, g.P, FAST ? smem + wave * (T::NPB * 1024) : nullptr);
+  } else {
+    Epi::template apply<T::NFB, T::NPB, FAST>(acc, ea, pre, f0 + wf, p0 + wp, lane, g.F, g.P);
+  }
 }
 
 // element (fb, reg) of a lane's fragment is feature  f_wave + 32*fb + 8*(reg>>2) + 4*h + (reg&3)

@@ -273,7 +273,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
       for (int j = 0; j < NPIECE; ++j) stage_piece(cn, j);
     }
     counted_wait = Epi::COUNTED_STORES && (p0 + T::BP <= g.P) && (f0 + T::BF <= g.F);
-    Epi::template apply<T::NFB, T::NPB, true>(acc, ea, pre, f0 + wf, p0 + wp, lane, g.F, g.P);
+    if constexpr (Epi::XBUF) {
+      // the wave's share of the second operand buffers (idle from the K loop's last barrier until the next tile's second K stage)
+      constexpr int XR = T::NPB * 1024;
+      static_assert(G::A_ELEMS % XR == 0 && 4 * XR <= G::A_ELEMS + G::B_ELEMS, "transposer regions must tile the idle buffers");
+      const int xo = wave * XR;
+      float* const xb = xo < G::A_ELEMS ? As1 + xo : Bs1 + (xo - G::A_ELEMS);
+      Epi::template apply<T::NFB, T::NPB, true>(acc, ea, pre, f0 + wf, p0 + wp, lane, g.F, g.P, xb);
+    } else {
+      Epi::template apply<T::NFB, T::NPB, true>(acc, ea, pre, f0 + wf, p0 + wp, lane, g.F, g.P);
+    }
   }
   if (g.stamps) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // include the store drain in the last interval
