@@ -201,7 +201,10 @@ def train_leg(dev, dist, world, rank, steps, backend):
         mixed = tr.mixup({"data": data[sl], "conditions": cond[sl], "survival": surv[sl]})
         return tr.train_step(mixed["data"], mixed["conditions"], comm_events=ev[i] if timed else None)
 
-    for i in range(5):
+    # 20 untimed steps: the first few pay one-off costs (kernel loading, work-list uploads, allocator growth), and on every box
+    # one more host-side stall of ~4 ms shows up between steps 10 and 15 (tools/probes/train_steps.py); from step 15 on the
+    # step time is flat
+    for i in range(20):
         one(i, False)
     torch.cuda.synchronize()
     if dist is not None:
