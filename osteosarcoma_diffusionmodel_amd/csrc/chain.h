@@ -567,7 +567,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
         const bool has_next = same_layer || l + 1 < a.n_layers;
         const int ln_next = same_layer ? l : l + 1;
         const int f0_next = same_layer ? f0 + T::BF : 0;
-        if (has_next) first_stage(a.L[ln_next], f0_next, true, false, pcur ^ 1);
+        // ... and, inside a layer, its activation stage too (the layer's own input panel, not touched by this epilogue): both DMAs
+        // are then OLDER than the epilogue's stores, so a counted wait can release the tile while the stores are still draining.
+        // (Staging the NEXT layer's first activation stage early as well -- it only depends on feature tile 0 of this layer --
+        // was measured: no gain, so a layer boundary keeps its plain drain + barrier + stage sequence.)
+        const bool early_b = same_layer;
+        if (has_next) first_stage(a.L[ln_next], f0_next, true, early_b, pcur ^ 1);
         const int fw = f0 + wf;
         const float* const prm = prm_base + pcur * CHAIN_PRM_FLOATS;
         pcur ^= 1;
@@ -595,11 +600,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
         if (CHAIN_EPI_PRIO) __builtin_amdgcn_s_setprio(0);
         unsigned long long tt3 = 0, te1 = 0, te2 = 0, te3 = 0, te4 = 0;
         if constexpr (STAMP) te1 = __builtin_amdgcn_s_memtime();
-        if (same_layer) {
-          // same input panel, not touched by this epilogue: its first K stage goes out behind the stores, ONE wait covers both
-          first_stage(a.L[ln_next], f0_next, false, true, 0);
+        if (early_b) {
           if constexpr (STAMP) tt3 = __builtin_amdgcn_s_memtime();
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          // the GroupNorm and input_proj epilogues issue at least 16 unguarded vector-memory operations per wave after the DMAs
+          // (8 * NFB * NPB / 2 stores; input_proj also 16 loads): vmcnt(16) = the DMAs have landed; the stores drain under the
+          // next K step, whose closing vmcnt(0) collects them.  The posterior epilogue's count depends on guards: full wait.
+          static_assert(4 * T::NFB * T::NPB == 16, "counted wait below is written for 16 stores");
+          if (L.kind != CK_POST) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if constexpr (STAMP) te2 = __builtin_amdgcn_s_memtime();
           __syncthreads();
           if constexpr (STAMP) te3 = te4 = __builtin_amdgcn_s_memtime();
