@@ -18,10 +18,8 @@ namespace osd {
 // the kernel's cycles).  Folding row >> 3 in makes the fragment-side read, the row-side read and both writes conflict-free.
 // LDS instructions of one wave execute in order, so a block's reads follow its writes (and the next block's writes follow these
 // reads) without any barrier; the compiler keeps the order because the accesses may alias.
-// The chain kernel's argument block lives in memory, so every pointer loaded from it is a GENERIC pointer to hipcc and an
-// access through it becomes a FLAT instruction (both counters, out-of-order return: every wait degrades to vmcnt(0) &
-// lgkmcnt(0), and the LDS pipe is involved in a global access).  The epilogues therefore go through the explicitly global
-// accessors ldg4 / stg4 / stg1 of gemm_glds.h (same box: 22.42 k -> 22.80 k patients/s).
+// Global memory is reached through ldg4 / stg4 (gemm_glds.h): explicitly global accesses even where hipcc only sees a generic
+// pointer.
 
 __device__ __forceinline__ int xsw(int row) { return (row ^ (row >> 3)) & 7; }
 template <int NPB>
