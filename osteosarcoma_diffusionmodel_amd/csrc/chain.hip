@@ -56,7 +56,10 @@ int chain_pick_engine(osd_handle* h, int64_t n, int flags) {
   int max_grid = 0;
   if (chain_device_limits(h->cfg.device, &max_grid) != OSD_OK || max_grid < 2) return 0;
   const int64_t n_tiles = (n + ChainTile::BP - 1) / ChainTile::BP;
-  return n_tiles * 4 >= (int64_t)max_grid * 3 ? 1 : 0;                        // at least 3/4 of the slots get a tile
+  // every slot gets a tile: with fewer tiles than resident workgroups the chain kernel idles CUs (384 tiles: 19.4 M
+  // patient-steps/s against 21.8 M for the per-layer engine, which also tiles the features; 512 tiles: 22.2 vs 22.1; beyond
+  // that the chain kernel leads -- tools/probes/engine_crossover.py)
+  return n_tiles >= (int64_t)max_grid ? 1 : 0;
 }
 
 static int ensure_buf(float** p, int64_t* cap, int64_t floats, hipStream_t s) {
