@@ -256,24 +256,37 @@ __device__ __forceinline__ void chain_posterior(f32x16 (&acc)[NFB][NPB], const f
 #ifndef CHAIN_EPI_PRIO
 #define CHAIN_EPI_PRIO 0
 #endif
+#ifndef CHAIN_BP
+#define CHAIN_BP 128
+#endif
+#if CHAIN_BP == 128
 typedef Tile<128, 128, 64, 64> ChainTile;            // 4 waves, 64 x 64 accumulators each (64 VGPRs), 2 waves per SIMD
+constexpr int CHAIN_WPS = 2;                         // workgroups per CU = waves per SIMD
+#else
+// make CXXFLAGS+=-DCHAIN_BP=64: 64-row tiles, 64 x 32 per wave (167 VGPRs, 52 KB of LDS), THREE workgroups per CU.  Bit-identical;
+// measured 22.25 k against 23.17 k patients/s for the default on the same box: half the MFMAs per tile against the same
+// per-tile latencies, twice the weight traffic per row.  Kept as a build option for that experiment only.
+typedef Tile<128, 64, 64, 32> ChainTile;
+constexpr int CHAIN_WPS = 3;
+#endif
 // tiles | flag word (16 B) | 40 per-kind counters of the diagnostic builds | two per-feature parameter blocks (double-buffered over tiles)
-constexpr int CHAIN_PRM_OFF = 2 * (128 * BK + 128 * BK) + 4 + 80;      // floats
+constexpr int CHAIN_PRM_OFF = 2 * (ChainTile::BF * BK + ChainTile::BP * BK) + 4 + 80;      // floats
 constexpr int CHAIN_LDS_BYTES = (CHAIN_PRM_OFF + 2 * CHAIN_PRM_FLOATS) * 4;
 static_assert(CHAIN_PRM_OFF % 4 == 0, "parameter blocks are read as float4");
 
 // STAMP (diagnostic builds only, make DIAG=1): per-workgroup cycle counters; the product kernel carries none of that state.
 template <bool STAMP>
-__global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __restrict__ gp) {
+__global__ __launch_bounds__(NTHREADS, CHAIN_WPS) void chain_kernel(const ChainArgs* __restrict__ gp) {
   // The argument block lives in device memory (uniform scalar loads).  Passed by value, hipcc hoists the loads of all ~60
   // fields to the kernel entry and keeps them in SGPRs for the whole kernel; the spills of that end up in VGPRs.  Each phase
   // therefore re-derives its pointer to the block through an empty asm, so a field is loaded where it is used.
   const ChainArgs& a = *gp;
   typedef ChainTile T;
   typedef GldsTile<T> G;
-  static_assert(T::BF == 128 && T::BP == 128, "staging below assumes 128-row operand images");
+  static_assert(T::BF == 128 && T::BP % 32 == 0, "staging below assumes a 128-row weight image");
   constexpr int NW = NTHREADS / 64;         // waves
-  constexpr int NPW = 16 / NW;              // 1 KiB DMA pieces (8 rows x 32 k) per wave and operand: wave w moves pieces w, w + NW, ...
+  constexpr int NPW = 16 / NW;              // 1 KiB DMA pieces (8 rows x 32 k) per wave of the weight image: wave w moves pieces w, w + NW, ...
+  constexpr int NPWB = T::BP / 8 / NW;      // ... and of the activation image
   constexpr int PROWS = 8 * NW;             // rows between two pieces of a wave
   constexpr unsigned PBYTES = 1024u * NW;   // LDS bytes between them
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
         const int kend = Ln.K0 < Ln.K ? Ln.K0 : Ln.K;
         const int k = k4 < kend - 4 ? k4 : kend - 4;
 #pragma unroll
-        for (int j = 0; j < NPW; ++j) {
+        for (int j = 0; j < NPWB; ++j) {
           int rg = r0 + PROWS * j;
           rg = rg < rows ? rg : rows - 1;
           glds16(bb + (size_t)rg * Ln.ld0 + k, __builtin_amdgcn_readfirstlane(lb + (unsigned)j * PBYTES));
@@ -457,12 +470,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
         for (int pb = 0; pb < T::NPB; ++pb) { const int R = wp + 32 * pb + l31; b_rd[pb] = R * BK; b_sw[pb] = h ^ ((R >> 1) & 7); }
         // ---- staging: direct global -> LDS DMA, XOR-swizzled 16-byte chunks (gemm_glds.h).  Per-lane byte offsets of the four
         // pieces are fixed for the tile (row clamps folded in); a K step only moves the wave-uniform bases (scalar adds) ----
-        unsigned offA[NPW], offB[NPW];
+        unsigned offA[NPW], offB[NPWB];
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
           int rg = f0 + st_row[j];
           rg = rg < F ? rg : F - 1;
           offA[j] = (unsigned)(rg * Llda + st_k4[j]) * 4u;
+        }
+#pragma unroll
+        for (int j = 0; j < NPWB; ++j) {
           int rb = st_row[j];
           rb = rb < rowsB ? rb : rowsB - 1;
           offB[j] = (unsigned)(rb * Lld0 + st_k4[j]) * 4u;
@@ -500,7 +516,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
             b_panel = want;
             const int ld = want ? Lld1 : Lld0;
 #pragma unroll
-            for (int j = 0; j < NPW; ++j) {
+            for (int j = 0; j < NPWB; ++j) {
               int rb = st_row[j];
               rb = rb < rowsB ? rb : rowsB - 1;
               offB[j] = (unsigned)(rb * ld + st_k4[j]) * 4u;
@@ -547,10 +563,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
                   acc[fb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[fb][e], bv[pb][e], acc[fb][pb], 0, 0, 0);
               // the DMA of the next K tile goes out in the first quarter of the step (two pieces per k-pair group): it then
               // has three quarters of the step to land before the barrier (gemm_glds.h)
-              if (i == 0 && more && 2 * e < 2 * NPW) {
+              if (i == 0 && more && 2 * e < NPW + NPWB) {
                 __builtin_amdgcn_sched_barrier(0);
                 stage(kn, An, Bn, 2 * e);
-                stage(kn, An, Bn, 2 * e + 1);
+                if (2 * e + 1 < NPW + NPWB) stage(kn, An, Bn, 2 * e + 1);
                 __builtin_amdgcn_sched_barrier(0);
               }
             }
@@ -605,9 +621,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void chain_kernel(const ChainArgs* __r
           // the GroupNorm and input_proj epilogues issue at least 16 unguarded vector-memory operations per wave after the DMAs
           // (8 * NFB * NPB / 2 stores; input_proj also 16 loads): vmcnt(16) = the DMAs have landed; the stores drain under the
           // next K step, whose closing vmcnt(0) collects them.  The posterior epilogue's count depends on guards: full wait.
-          static_assert(4 * T::NFB * T::NPB == 16, "counted wait below is written for 16 stores");
-          if (L.kind != CK_POST) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          static_assert(4 * T::NFB * T::NPB == 16 || 4 * T::NFB * T::NPB == 8, "counted wait below is written for 16 or 8 stores");
+          if (L.kind == CK_POST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (4 * T::NFB * T::NPB == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
           if constexpr (STAMP) te2 = __builtin_amdgcn_s_memtime();
           __syncthreads();
           if constexpr (STAMP) te3 = te4 = __builtin_amdgcn_s_memtime();

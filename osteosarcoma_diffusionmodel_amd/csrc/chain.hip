@@ -39,7 +39,7 @@ static int chain_device_limits(int device, int* max_grid) {
     OSD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, chain_kernel<false>, NTHREADS, CHAIN_LDS_BYTES));
     hipDeviceProp_t prop;
     OSD_HIP(hipGetDeviceProperties(&prop, device));
-    d.occ = occ < 2 ? occ : 2;              // two 64 KB tiles per CU by design
+    d.occ = occ < CHAIN_WPS ? occ : CHAIN_WPS;      // two 64 KB tiles per CU by design
     d.cus = prop.multiProcessorCount;
     d.ready = true;
   }
