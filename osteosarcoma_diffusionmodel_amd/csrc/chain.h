@@ -4,24 +4,29 @@
 // row).  The per-layer kernels of gemm_glds.h pay, 12 times per step, a launch boundary, a wave of workgroups that all
 // sit in their prologue (then their epilogue) at the same moment, and a partial last round.  Here the unit of work is
 // (128-row tile, one step): a workgroup carries its tile through input_proj, the ten Linear+GroupNorm+SiLU layers and
-// output_proj + posterior update with the same MFMA tile loop and the same epilogues as the per-layer kernels; the
+// output_proj + posterior update with the same MFMA tile loop and the same epilogue arithmetic as the per-layer kernels
+// (the two engines agree bitwise); the
 // activations of the tile live in a workspace PRIVATE to the workgroup's slot (written and re-read by one CU: L2 /
 // Infinity-Cache traffic, never another workgroup's business), the chain state x stays in the caller's [n][D] tensor.
 //
-// Units are dealt round-robin: workgroup w runs units w, w + G, w + 2G, ... in order, unit u = (tile u % n_tiles,
-// step u / n_tiles).  A unit needs x_t of its tile, written by the unit n_tiles earlier (another workgroup, possibly
-// another XCD): the producer publishes with an agent-scope release behind a drained workgroup barrier and a relaxed
-// agent store of progress[tile]; the consumer polls that one word relaxed from one lane, then ONE agent-scope acquire,
-// s_waitcnt, workgroup barrier, plain loads (cdna_hip_programming.md Guideline 16).  With G <= n_tiles the producer
-// is at least one full round of units ahead, so the poll normally passes at once; dependencies always point to an
-// earlier unit in the global order, hence no cycle as long as the G workgroups are resident (the host sizes G by the
-// occupancy query).  Every spin is bounded by a wall-clock budget: on expiry the workgroup raises status[0] and
-// leaves; every other workgroup sees the flag at its next unit (or in its own spin) and leaves too.
+// Units are taken from ONE atomic counter in global order, unit u = (tile u % n_tiles, step u / n_tiles): whoever is free takes
+// the next one (the two workgroups of a CU do not run at the same speed: the SIMD arbiter favours the older waves).  A unit needs
+// x_t of its tile, written by the unit n_tiles earlier (another workgroup, possibly another XCD): the producer publishes with an
+// agent-scope release behind a drained workgroup barrier and a relaxed agent store of progress[tile]; the consumer polls that
+// one word relaxed from one wave (wave-uniform control flow), then ONE agent-scope acquire, s_waitcnt, workgroup barrier,
+// plain loads (cdna_hip_programming.md Guideline 16).  Every dependency points to a unit that was taken earlier by a
+// workgroup that is running, so there is no cycle and no wait on a workgroup that is not resident; with n_tiles >= G the
+// producer is a full round ahead and the poll normally passes at once (measured: 0.13 % of a workgroup's cycles).  Every spin
+// is bounded by a wall-clock budget: on expiry the workgroup raises status[0] and leaves; every other workgroup sees the flag
+// at its next unit (or in its own spin) and leaves too.
 //
-// Balance: n_tiles * T units over G = 2 per CU workgroups differ by at most one unit (2 ms of a 4 s chain), there is
-// no kernel boundary, and the two workgroups of a CU are started half a short tile apart (the second arrival on a CU
-// sleeps `stagger` cycles once) so that one's prologue / epilogue falls into the other's MFMA loop instead of both
-// idling the matrix pipe together -- the phase lock of identical co-resident workgroups is otherwise stable.
+// Epilogues (xpose.h, below): per-feature parameters arrive in LDS by DMA with the tile's first weight stage; outputs leave and
+// x_t / cond_proj arrive as full 128-byte row segments through a per-wave LDS transposer in the idle second operand buffer;
+// global accesses are explicit (the argument block lives in memory, so its pointers are generic to hipcc).
+//
+// `stagger` (the second workgroup to arrive on a CU waits that many cycles once) is kept as a knob: 0 ... 120 000 cycles all
+// measure within +-0.3 % -- the phases of the two workgroups drift anyway (DESIGN.md section 3.2 for what does and does not
+// move this kernel: per SIMD its time is MFMA cycles + VALU cycles + the stalls that hit both workgroups at once).
 #pragma once
 #include "gemm_glds.h"
 #include "epilogues.h"
