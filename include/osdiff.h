@@ -88,7 +88,11 @@ int osd_set_stream(osd_handle *h, void *hip_stream);
 /* Tunables: "sampler" (0 auto, 1 persistent chain kernel wherever the architecture allows it, 2 per-layer kernels),
  * "chunk_rows" / "n_streams" (per-layer path: rows per sampling chunk, chunks in flight), "chain_grid" (cap on the chain
  * kernel's workgroups), "chain_steps_per_launch" (0 = the whole chain in one launch), "chain_stagger" (shader cycles
- * between the starts of the two workgroups of a CU), "train_streams" (1 | 2: weight gradients on a side stream). */
+ * between the starts of the two workgroups of a CU), "train_streams" (1 | 2: weight-gradient leaves on a side stream),
+ * "grouped_wgrad" (1: every weight gradient of a backward pass in one grouped launch), "wgrad_mid_flush" (1: the decoder
+ * half's weight gradients already mid-pass; always on under data parallel), "fused_gn_bwd" (1: GroupNorm backward inside
+ * the dgrad epilogue).  Auto sampler: the chain kernel when the batch has at least as many 128-row tiles as the device
+ * holds resident workgroups (65 536 rows on an MI355X) and the model is in eval mode, else the per-layer kernels. */
 int osd_set_option(osd_handle *h, const char *name, int64_t value);
 
 /* Schedule + time-embedding tables, computed by the host with the reference's own
