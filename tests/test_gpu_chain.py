@@ -100,3 +100,25 @@ def test_chain_kernel_other_widths_and_fallbacks():
     assert L.lib().osd_sample_engine(eng.handle, 4096, 0) == 0
     assert L.lib().osd_sample_engine(eng.handle, 100_000, 0) == 1
     assert L.lib().osd_sample_engine(eng.handle, 100_000, L.OSD_F_TRAIN_MODE) == 0
+
+
+@pytest.mark.parametrize("dims,hidden,n", [
+    (dict(mutation_dim=7, expression_dim=121, pathway_dim=4, condition_dim=4), [256, 256], 129),           # D = 132: one ragged 128-feature tile + 4
+    (dict(mutation_dim=50, expression_dim=200, pathway_dim=10, condition_dim=3), [512, 512, 512], 300),    # D = 260; 512-wide everywhere
+    (dict(mutation_dim=33, expression_dim=1, pathway_dim=2, condition_dim=2), [256, 512, 512, 256], 1),    # D = 36 < one tile, a single row
+    (dict(mutation_dim=3, expression_dim=2040, pathway_dim=5, condition_dim=3), [256, 512, 256], 127),     # D = 2048: whole feature tiles
+])
+def test_chain_kernel_edge_shapes_bitwise(dims, hidden, n):
+    """Feature counts that are not multiples of the 128-wide output tile (the posterior epilogue's parameter DMA, x_t row
+    segments and stores are clamped / guarded there), mutation widths that are not multiples of 4 (mask at t = 0), row counts
+    of 1 / 127 / 129, four- and eight-layer trunks: the chain kernel against the per-layer kernels, bit for bit."""
+    T = 6
+    m = _model(T, hidden=hidden, seed=7, **dims)
+    cond = torch.randn(n, dims["condition_dim"], generator=torch.Generator().manual_seed(2)).cuda()
+    ref, ref_mask = _run(m, cond, n, "graph", seed=11, row_offset=3)
+    m.chain_grid = 2
+    out, mask = _run(m, cond, n, "chain", seed=11, row_offset=3)
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, ref), f"max|d| = {(out - ref).abs().max().item():.3e}"
+    assert torch.equal(mask, ref_mask)
+
