@@ -9,6 +9,8 @@ struct ZeroList { float* ptr[128]; int64_t count[128]; int n; };
 hipError_t launch_zero_many(hipStream_t s, const ZeroList& zl);
 
 hipError_t launch_silu_fwd(hipStream_t s, const float* u, float* y, int64_t total);
+hipError_t launch_cond_mlp_fwd(hipStream_t s, const float* cond, int cd, const float* w0, const float* b0, const float* w2, const float* b2, int64_t n,
+                               float* u0, float* ce1, float* ce2);
 hipError_t launch_silu_bwd(hipStream_t s, const float* u, const float* g, float* gu, int64_t total);
 hipError_t launch_colsum(hipStream_t s, const float* in, int ld, int64_t rows, int cols, float* out);
 hipError_t launch_scatter_rows(hipStream_t s, const float* g, const int* t, int64_t rows, int cols, float* table);

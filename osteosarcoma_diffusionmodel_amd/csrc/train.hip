@@ -114,13 +114,11 @@ static int ensure_train_ws(osd_handle* h, hipStream_t s, int64_t n, const ConsPl
 static int cond_embed_fwd(osd_handle* h, hipStream_t s, const float* cond, int64_t n, TrainWs& w) {
   const Arch& a = h->arch;
   const ParamMap& pm = a.pm;
+  // the two 64-wide layers and the SiLU between them in one launch (k_cond_mlp_fwd), cond_proj on the tile GEMM
+  OSD_HIP(launch_cond_mlp_fwd(s, cond, a.cond_dim, h->params[pm.ce0_w], h->params[pm.ce0_b], h->params[pm.ce2_w], h->params[pm.ce2_b], n,
+                              w.u0, w.f.ce1, w.f.ce2));
   GemmArgs g{};
-  g.A = h->params[pm.ce0_w]; g.lda = a.cond_dim; g.B0 = cond; g.ldb0 = a.cond_dim; g.K0 = a.cond_dim; g.F = 64; g.P = (int)n; g.K = a.cond_dim;
-  OSD_HIP(launch_linear(s, g, true, true, h->params[pm.ce0_b], w.u0, 64, false, false));
-  OSD_HIP(launch_silu_fwd(s, w.u0, w.f.ce1, n * 64));
-  g.A = h->params[pm.ce2_w]; g.lda = 64; g.B0 = w.f.ce1; g.ldb0 = 64; g.K0 = 64; g.K = 64;
-  OSD_HIP(launch_linear(s, g, true, true, h->params[pm.ce2_b], w.f.ce2, 64, false, false));
-  g.A = h->params[pm.cp_w]; g.B0 = w.f.ce2; g.F = a.H0;
+  g.A = h->params[pm.cp_w]; g.lda = 64; g.B0 = w.f.ce2; g.ldb0 = 64; g.K0 = 64; g.K = 64; g.P = (int)n; g.F = a.H0;
   OSD_HIP(launch_linear(s, g, true, true, h->params[pm.cp_b], w.f.cproj, a.H0, false, false));
   return OSD_OK;
 }
