@@ -549,7 +549,12 @@ def prepare_data(config: dict):
     val_size = int(len(dataset) * tc["val_split"])
     train_ds, val_ds = torch.utils.data.random_split(dataset, [len(dataset) - val_size, val_size],
                                                      generator=torch.Generator().manual_seed(tc["random_seed"]))
-    train_loader = DataLoader(train_ds, batch_size=tc["batch_size"], shuffle=True, num_workers=0, drop_last=True)
+    # data parallel (torch.distributed initialised, world > 1): the train split is the same on every rank (seeded), each rank
+    # then draws its own 1/world of it per epoch -- `batch_size` is per rank, as in the reference's single process
+    sampler = None
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        sampler = torch.utils.data.distributed.DistributedSampler(train_ds, shuffle=True, seed=tc["random_seed"], drop_last=True)
+    train_loader = DataLoader(train_ds, batch_size=tc["batch_size"], shuffle=sampler is None, sampler=sampler, num_workers=0, drop_last=True)
     val_loader = DataLoader(val_ds, batch_size=tc["batch_size"], shuffle=False, num_workers=0)
     config["model"]["n_genes_mutation"] = mutation_matrix.shape[1]
     config["model"]["n_genes_expression"] = expression_matrix.shape[1]

@@ -198,3 +198,58 @@ def test_shardcomm_inactive_is_identity():
     assert not c.on and c.world == 1
     assert c.gather_rows(t) is t and list(c.shards(t))[0] is t
     assert c.sum(5).tolist() == [5] and c.bcast_object("a") == "a"
+
+
+def _prep_worker(rank, world, port, root, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from osteosarcoma_diffusionmodel_amd.train import prepare_data
+        conf = {"data": {"processed_dir": root}, "model": {},
+                "training": {"batch_size": 8, "val_split": 0.2, "random_seed": 42}}
+        train_loader, val_loader, conf = prepare_data(conf)
+        seen = []
+        for batch in train_loader:
+            seen.append(batch["data"][:, 6:16].clone())         # the expression block: real-valued, identifies a row
+        rows = torch.cat(seen)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, rows.numpy().tolist())
+        q.put((rank, len(train_loader), everyone if rank == 0 else None, conf["model"]["n_conditions"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_prepare_data_shards_the_train_split_gloo_world2(tmp_path):
+    """utils/train.py:342-444 under data parallel: every rank loads the same files and makes the same seeded train /
+    validation split; the DistributedSampler then hands each rank its own half of the train rows per epoch (batch_size is
+    per rank), so the ranks' batches are disjoint."""
+    import pandas as pd
+    rng = np.random.RandomState(0)
+    n, root = 100, tmp_path / "processed"
+    root.mkdir()
+    ids = [f"TARGET-40-{i:04d}" for i in range(n)]
+    pd.DataFrame(rng.randint(0, 2, (n, 6)), index=ids, columns=[f"G{i}" for i in range(6)]).to_csv(root / "mutation_matrix_aligned.csv")
+    pd.DataFrame(rng.randn(n, 10), index=ids, columns=[f"E{i}" for i in range(10)]).to_csv(root / "expression_matrix_aligned.csv")
+    pd.DataFrame(rng.randn(n, 4), index=ids, columns=[f"P{i}" for i in range(4)]).to_csv(root / "pathway_scores.csv")
+    pd.DataFrame({"submitter_id": ids, "survival_days": rng.randint(100, 2000, n), "event_occurred": rng.randint(0, 2, n),
+                  "age_years": rng.uniform(10, 18, n)}).to_csv(root / "clinical_aligned.csv", index=False)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_prep_worker, args=(r, 2, port, str(root), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(30)
+    assert res[0][1] == res[1][1] == 5                     # 80 train rows -> 40 per rank -> 5 batches of 8
+    assert res[0][3] == 3                                  # survival_days_norm, event_occurred, age_years
+    everyone = res[0][2]
+    assert len(everyone[0]) == len(everyone[1]) == 40
+    r0 = {tuple(np.round(v, 5)) for v in everyone[0]}
+    r1 = {tuple(np.round(v, 5)) for v in everyone[1]}
+    assert len(r0) == len(r1) == 40 and not (r0 & r1)      # disjoint halves of the 80-row train split
+
