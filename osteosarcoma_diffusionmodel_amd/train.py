@@ -508,6 +508,9 @@ class Trainer:
         tc = self.config["training"]
         for epoch in range(tc["num_epochs"]):
             logger.info(f"\nEpoch {epoch + 1}/{tc['num_epochs']}")
+            sampler = getattr(self.train_loader, "sampler", None)
+            if hasattr(sampler, "set_epoch"):           # DistributedSampler (prepare_data under data parallel): reshuffle per epoch
+                sampler.set_epoch(epoch)
             train_loss = self.train_epoch()
             self.history["train_loss"].append(train_loss)
             val_loss = self.validate()
