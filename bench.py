@@ -199,7 +199,9 @@ def train_leg(dev, dist, world, rank, steps, backend):
         o = (i * B) % (rows - B)
         sl = slice(o, o + B)
         mixed = tr.mixup({"data": data[sl], "conditions": cond[sl], "survival": surv[sl]})
-        return tr.train_step(mixed["data"], mixed["conditions"], comm_events=ev[i] if timed else None)
+        # the exposed-communication event pair only exists under data parallel: two timing events cost the single-GPU step
+        # two barrier packets (~10 us) for a number that is zero by construction
+        return tr.train_step(mixed["data"], mixed["conditions"], comm_events=ev[i] if (timed and world > 1) else None)
 
     # 20 untimed steps: the first few pay one-off costs (kernel loading, work-list uploads, allocator growth), and on every box
     # one more host-side stall of ~4 ms shows up between steps 10 and 15 (tools/probes/train_steps.py); from step 15 on the
