@@ -555,7 +555,12 @@ struct EpiMse {
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-      if (lane == 0) atomicAdd(a.loss, part * a.inv_count);
+      // one atomic per workgroup (the four waves meet in LDS): same-address float atomics serialise in L2
+      __shared__ float wave_part[4];               // 16 bytes: keeps the dynamic LDS base 16-byte aligned
+      const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+      if (lane == 0) wave_part[wv] = part;
+      __syncthreads();
+      if (threadIdx.x == 0) atomicAdd(a.loss, ((wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3])) * a.inv_count);
       return;
     }
     OSD_FOR_QUADS(fb, pb, q) {
