@@ -633,7 +633,12 @@ struct EpiRbfSum {
     double dp = (double)part;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dp += __shfl_xor(dp, o);
-    if (lane == 0) atomicAdd(a.sum, dp);
+    // one atomic per workgroup: a 50 000 x 50 000 Gram block is 153 000 tiles, and same-address atomics serialise in L2
+    __shared__ double wave_sum[4];                 // 32 bytes: the dynamic LDS base stays 16-byte aligned
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (lane == 0) wave_sum[wv] = dp;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(a.sum, (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]));
   }
 };
 
