@@ -593,6 +593,9 @@ struct EpiRbfSum {
   static constexpr bool COUNTED_STORES = false;   // stores nothing
   static constexpr bool XBUF = false;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
+  // sum: RBF_SLOTS doubles; a workgroup adds into slot blockIdx.x % RBF_SLOTS (same-address atomics serialise in L2: 153 000
+  // tiles of a 50 000 x 50 000 block on ONE address cost ~2 % of the kernel), the host adds the slots up
+  static constexpr int RBF_SLOTS = 256;
   struct Args { const float* sqa; const float* sqb; float gamma; double* sum; };
   static bool fast_ok(const Args& a, int F) { return F % 4 == 0 && al16(a.sqa); }
   template <int NFB> struct Pre { float4 sqa[NFB][4]; };
@@ -638,7 +641,7 @@ struct EpiRbfSum {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (lane == 0) wave_sum[wv] = dp;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(a.sum, (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]));
+    if (threadIdx.x == 0) atomicAdd(a.sum + (blockIdx.x % RBF_SLOTS), (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]));
   }
 };
 

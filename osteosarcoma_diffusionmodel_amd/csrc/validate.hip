@@ -151,20 +151,24 @@ int osd_val_mmd(void* stream, int device, const float* X, int64_t n, const float
   hipStream_t s = (hipStream_t)stream;
   DevBuf sq, sums;
   OSD_HIP(sq.alloc((size_t)(n + m) * 4));
-  OSD_HIP(sums.alloc(3 * sizeof(double)));
+  constexpr int NS = EpiRbfSum::RBF_SLOTS;
+  OSD_HIP(sums.alloc(3 * NS * sizeof(double)));
   float* sqx = (float*)sq.p;
   float* sqy = sqx + n;
   double* d = (double*)sums.p;
-  OSD_HIP(hipMemsetAsync(d, 0, 3 * sizeof(double), s));
+  OSD_HIP(hipMemsetAsync(d, 0, 3 * NS * sizeof(double), s));
   hipLaunchKernelGGL(k_rowsumsq, 1024, 256, 0, s, X, n, D, sqx);
   hipLaunchKernelGGL(k_rowsumsq, 1024, 256, 0, s, Y, m, D, sqy);
   if (gamma <= 0) gamma = 1.0 / D;                                  // utils/validation.py:283-284
   OSD_HIP(rbf_sum(s, X, n, sqx, X, n, sqx, D, (float)gamma, d));
-  OSD_HIP(rbf_sum(s, Y, m, sqy, Y, m, sqy, D, (float)gamma, d + 1));
-  OSD_HIP(rbf_sum(s, X, n, sqx, Y, m, sqy, D, (float)gamma, d + 2));
-  double h[3];
-  OSD_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s));
+  OSD_HIP(rbf_sum(s, Y, m, sqy, Y, m, sqy, D, (float)gamma, d + NS));
+  OSD_HIP(rbf_sum(s, X, n, sqx, Y, m, sqy, D, (float)gamma, d + 2 * NS));
+  std::vector<double> slots(3 * NS);
+  OSD_HIP(hipMemcpyAsync(slots.data(), d, slots.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   OSD_HIP(hipStreamSynchronize(s));
+  double h[3] = {0.0, 0.0, 0.0};
+  for (int k = 0; k < 3; ++k)
+    for (int i = 0; i < NS; ++i) h[k] += slots[(size_t)k * NS + i];
   const double v = h[0] / ((double)n * n) + h[1] / ((double)m * m) - 2.0 * h[2] / ((double)n * m);
   *mmd_out = sqrt(v > 0 ? v : 0.0);
   return OSD_OK;
@@ -177,15 +181,20 @@ int osd_val_rbf_sum(void* stream, int device, const float* A, int64_t n, const f
   hipStream_t s = (hipStream_t)stream;
   DevBuf sq, sums;
   OSD_HIP(sq.alloc((size_t)(n + m) * 4));
-  OSD_HIP(sums.alloc(sizeof(double)));
+  constexpr int NS = EpiRbfSum::RBF_SLOTS;
+  OSD_HIP(sums.alloc(NS * sizeof(double)));
   float* sqa = (float*)sq.p;
   float* sqb = sqa + n;
-  OSD_HIP(hipMemsetAsync(sums.p, 0, sizeof(double), s));
+  OSD_HIP(hipMemsetAsync(sums.p, 0, NS * sizeof(double), s));
   hipLaunchKernelGGL(k_rowsumsq, 1024, 256, 0, s, A, n, D, sqa);
   hipLaunchKernelGGL(k_rowsumsq, 1024, 256, 0, s, B, m, D, sqb);
   OSD_HIP(rbf_sum(s, A, n, sqa, B, m, sqb, D, (float)gamma, (double*)sums.p));
-  OSD_HIP(hipMemcpyAsync(sum_out, sums.p, sizeof(double), hipMemcpyDeviceToHost, s));
+  std::vector<double> slots(NS);
+  OSD_HIP(hipMemcpyAsync(slots.data(), sums.p, NS * sizeof(double), hipMemcpyDeviceToHost, s));
   OSD_HIP(hipStreamSynchronize(s));
+  double t = 0.0;
+  for (double v : slots) t += v;
+  *sum_out = t;
   return OSD_OK;
 }
 
