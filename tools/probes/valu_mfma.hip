@@ -19,10 +19,15 @@ __global__ __launch_bounds__(512) void probe(int do_mfma, int other, int iters, 
       for (int i = 0; i < iters; ++i) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+          // do_mfma: 1 back to back; 2 an s_nop 0 after every MFMA; 3 an s_sleep 0; 4 s_sleep 1 after every fourth
           a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+          if (do_mfma == 2) asm volatile("s_nop 0"); else if (do_mfma == 3) __builtin_amdgcn_s_sleep(0);
           a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
+          if (do_mfma == 2) asm volatile("s_nop 0"); else if (do_mfma == 3) __builtin_amdgcn_s_sleep(0);
           a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a2, 0, 0, 0);
+          if (do_mfma == 2) asm volatile("s_nop 0"); else if (do_mfma == 3) __builtin_amdgcn_s_sleep(0);
           a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a3, 0, 0, 0);
+          if (do_mfma == 2) asm volatile("s_nop 0"); else if (do_mfma == 3) __builtin_amdgcn_s_sleep(0); else if (do_mfma == 4) __builtin_amdgcn_s_sleep(1);
         }
       }
       res = a0[0] + a1[1] + a2[2] + a3[3];
@@ -148,6 +153,16 @@ int main() {
       for (int g = 0; g < grid; ++g) { for (int w = 0; w < 4; ++w) a += h[g * 8 + w]; for (int w = 4; w < 8; ++w) b += h[g * 8 + w]; }
       a /= grid * 4.0 * iters; b /= grid * 4.0 * iters;
       printf("mfma %d  other %-34s : MFMA waves %8.1f cycles / 16 MFMAs (%.1f per MFMA)   other waves %8.1f cycles / iteration\n", do_mfma, names[other % 10], a, a / 16, b);
+    }
+  printf("-- MFMA wave yielding (2: s_nop 0 after every MFMA, 3: s_sleep 0, 4: s_sleep 1 after every fourth), other wave 16 v_fma_f32 / 8+8 LDS ops:\n");
+  for (int mode = 2; mode <= 4; ++mode)
+    for (int other : {1, 3}) {
+      for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(probe, dim3(grid), dim3(512), 100 * 1024, 0, mode, other, iters, out, sink); (void)hipDeviceSynchronize(); }
+      (void)hipMemcpy(h.data(), out, grid * 8 * 8, hipMemcpyDeviceToHost);
+      double a = 0, b = 0;
+      for (int g = 0; g < grid; ++g) { for (int w = 0; w < 4; ++w) a += h[g * 8 + w]; for (int w = 4; w < 8; ++w) b += h[g * 8 + w]; }
+      a /= grid * 4.0 * iters; b /= grid * 4.0 * iters;
+      printf("yield mode %d  other %-34s : MFMA waves %8.1f cycles / 16 MFMAs (%.1f per MFMA)   other waves %8.1f cycles / iteration\n", mode, names[other], a, a / 16, b);
     }
   run_same<0>(out, sink, h); run_same<1>(out, sink, h); run_same<2>(out, sink, h); run_same<4>(out, sink, h);
   run_same<8>(out, sink, h); run_same<12>(out, sink, h); run_same<16>(out, sink, h);
