@@ -95,6 +95,12 @@ int osd_set_stream(osd_handle *h, void *hip_stream);
  * holds resident workgroups (65 536 rows on an MI355X) and the model is in eval mode, else the per-layer kernels. */
 int osd_set_option(osd_handle *h, const char *name, int64_t value);
 
+/* Reads an option back, or one of the read-only counters "chain_fallbacks" (chains that gave up -- see osd_sample_chain --
+ * and were re-run on the per-layer kernels) and "last_engine" (0 per-layer kernels, 1 chain kernel).  Further options:
+ * "chain_spin_budget" (ticks of the 100 MHz s_memrealtime counter a dependency wait inside the chain kernel may take, default
+ * 5 s), "chain_wall_budget_ms" (host-side budget of a synchronous chain; 0 = 10 x the estimated run time + 2 s). */
+int osd_get_option(osd_handle *h, const char *name, int64_t *value);
+
 /* Schedule + time-embedding tables, computed by the host with the reference's own
  * fp32 expressions so they are bit-identical (models/diffusion.py:299-326, 131-137,
  * 401-419).  All host pointers:
@@ -144,8 +150,12 @@ int osd_sample_chain(osd_handle *h, const float *cond, int64_t n, const float *x
  * hipGraph under OSD_F_GRAPH) and, for >= ~50 000 rows of an architecture with 256/512-wide blocks in eval mode, ONE
  * persistent kernel that carries each 128-row tile through all layers and all T steps (csrc/chain.h).  Returns the
  * engine a call with these n / flags would use (0 per-layer, 1 chain kernel); n < 0: the engine of the last call.  The
- * chain kernel bounds every inter-workgroup wait; if a wait expires its results are invalid and the failure is reported
- * by the call itself under OSD_F_SYNC, else by the next osd_sample_chain on the handle (OSD_EHIP). */
+ * chain kernel bounds every inter-workgroup wait ("chain_spin_budget"), and a synchronous call bounds the kernel itself
+ * ("chain_wall_budget_ms": hipStreamQuery poll, then an abort flag the waits observe).  If the chain gives up its results are
+ * invalid: under OSD_F_SYNC the SAME call re-runs the chain on the per-layer kernels from x_T / seed (bit-identical results;
+ * returns OSD_OK, osd_last_error() holds a warning, "chain_fallbacks" counts, osd_sample_engine(h, -1, 0) then reports 0) --
+ * models/diffusion.py:427-449 cannot fail; without OSD_F_SYNC the next osd_sample_chain on the handle returns OSD_EHIP.
+ * OSD_EHIP from a synchronous call means the kernel did not even react to the abort flag (device hung). */
 int osd_sample_engine(osd_handle *h, int64_t n, int flags);
 
 /* Training forward+backward (models/diffusion.py:344-380 + loss.backward(),
@@ -216,9 +226,8 @@ int osd_clip_adamw_step(osd_handle *h, float *param, float *grad, float *exp_avg
                         double weight_decay, double max_norm, int64_t step, float *grad_norm_out);
 
 /* The same step without a model handle (any nn.Module's flat buffers, e.g. the cVAE): normsq_ws is
- * caller-owned device scratch of 8 doubles, ZEROED by the caller once: the two norm accumulators in it alternate
- * with the parity of `step` and each call zeroes the next one, so consecutive calls use consecutive steps
- * (re-zero the scratch before a call that does not follow the previous one). */
+ * caller-owned device scratch of 256 doubles (no initial state needed: the global gradient norm is formed from one partial
+ * sum per workgroup, added up in a fixed order -- deterministic, and independent of any previous call). */
 int osd_nn_clip_adamw_step(void *stream, int device, double *normsq_ws, float *param, float *grad,
                            float *exp_avg, float *exp_avg_sq, int64_t numel, double lr, double beta1,
                            double beta2, double eps, double weight_decay, double max_norm, int64_t step,

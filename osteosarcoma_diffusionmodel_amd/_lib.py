@@ -45,6 +45,7 @@ _SIGNATURES = {
     "osd_destroy": (C.c_int, [_P]),
     "osd_set_stream": (C.c_int, [_P, _P]),
     "osd_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "osd_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     "osd_set_schedule": (C.c_int, [_P, _P, _P, _P, _P]),
     "osd_load_weights": (C.c_int, [_P, C.POINTER(_P), C.c_int]),
     "osd_denoiser_forward": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int64, _P, C.c_int, C.POINTER(_P), C.c_uint64]),

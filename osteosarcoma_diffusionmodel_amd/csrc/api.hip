@@ -403,6 +403,16 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
     h->chain_grid = (int)value;
     return OSD_OK;
   }
+  if (!strcmp(name, "chain_spin_budget")) {       // s_memrealtime ticks (100 MHz) a dependency wait inside the chain kernel may take
+    if (value < 0) { set_error("chain_spin_budget must be >= 0"); return OSD_EINVAL; }
+    h->chain_spin_budget = (unsigned long long)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "chain_wall_budget_ms")) {    // host-side budget of a synchronous chain; 0 = 10 x the estimated run time + 2 s
+    if (value < 0) { set_error("chain_wall_budget_ms must be >= 0"); return OSD_EINVAL; }
+    h->chain_wall_budget_ms = value;
+    return OSD_OK;
+  }
   if (!strcmp(name, "chain_steps_per_launch")) {
     if (value < 0) { set_error("chain_steps_per_launch must be >= 0"); return OSD_EINVAL; }
     h->chain_steps_per_launch = (int)value;
@@ -433,6 +443,22 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
     h->two_stream_bwd = value == 2;
     return OSD_OK;
   }
+  set_error("unknown option '%s'", name);
+  return OSD_EINVAL;
+}
+
+int osd_get_option(osd_handle* h, const char* name, int64_t* value) {
+  if (!h || !name || !value) { set_error("null argument"); return OSD_EINVAL; }
+  struct { const char* n; int64_t v; } tab[] = {
+      {"chunk_rows", h->chunk_rows}, {"n_streams", h->n_streams}, {"sampler", h->sampler}, {"chain_grid", h->chain_grid},
+      {"chain_steps_per_launch", h->chain_steps_per_launch}, {"chain_stagger", h->chain_stagger},
+      {"chain_spin_budget", (int64_t)h->chain_spin_budget}, {"chain_wall_budget_ms", h->chain_wall_budget_ms},
+      {"grouped_wgrad", h->grouped_wgrad}, {"fused_gn_bwd", h->fused_gn_bwd}, {"wgrad_mid_flush", h->wgrad_mid_flush},
+      {"train_streams", h->two_stream_bwd ? 2 : 1},
+      // read-only counters
+      {"chain_fallbacks", h->chain_fallbacks}, {"last_engine", h->last_engine}};
+  for (const auto& e : tab)
+    if (!strcmp(name, e.n)) { *value = e.v; return OSD_OK; }
   set_error("unknown option '%s'", name);
   return OSD_EINVAL;
 }
@@ -628,10 +654,22 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
   OSD_HIP(hipSetDevice(h->cfg.device));
   OSD_TRY(chain_check_status(h));            // a previous chain-kernel run that gave up is reported here at the latest
   h->last_engine = chain_pick_engine(h, n, flags);
+  bool fell_back = false;
   if (h->last_engine == 1) {
     OSD_TRY(chain_run(h, cond, n, x_T, noises, seed, row_offset, x_out, mut_mask_out));
-    if (flags & OSD_F_SYNC) OSD_TRY(chain_check_status(h));
-    return OSD_OK;
+    if (!(flags & OSD_F_SYNC)) return OSD_OK;       // asynchronous: a chain that gives up is reported by the next call on this handle
+    int gave_up = 0;
+    OSD_TRY(chain_finish(h, &gave_up));
+    if (!gave_up) return OSD_OK;
+    // models/diffusion.py:427-449 cannot fail: the chain is re-run on the per-layer kernels, which compute the same bits from
+    // the same x_T / seed (the chain state lives in x_out, so an aliased x_T is gone)
+    if (x_T == x_out) {
+      set_error("the reverse-chain kernel gave up and x_T aliases x_out: nothing left to re-run the chain from");
+      return OSD_EHIP;
+    }
+    ++h->chain_fallbacks;
+    h->last_engine = 0;
+    fell_back = true;
   }
   // equal chunks (rounded up to whole 128-row tiles) of at most chunk_rows rows
   int64_t n_chunks = (n + h->chunk_rows - 1) / h->chunk_rows;
@@ -663,6 +701,8 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
   }
   if (rc != OSD_OK) return rc;
   if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(h->stream));
+  if (fell_back)       // a warning, not an error: osd_last_error() tells what happened, osd_get_option("chain_fallbacks") counts
+    set_error("warning: the reverse-chain kernel gave up in a dependency wait; the chain was re-run on the per-layer kernels (same results)");
   return OSD_OK;
 }
 

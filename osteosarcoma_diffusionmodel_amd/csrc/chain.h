@@ -37,7 +37,7 @@ namespace osd {
 
 constexpr int CHAIN_MAX_LAYERS = 24;
 enum : int { CK_INPUT = 0, CK_GN32 = 1, CK_GN64 = 2, CK_POST = 3 };
-enum : unsigned { CHAIN_OK = 0, CHAIN_TIMEOUT = 1 };
+enum : unsigned { CHAIN_OK = 0, CHAIN_TIMEOUT = 1, CHAIN_ABORT = 2 };     // ABORT: written by the host (wall-clock budget)
 
 struct ChainLayer {
   const float* A; int lda;        // weights [F][K], K contiguous, readable and zero for k in [K, roundup(K, 32))

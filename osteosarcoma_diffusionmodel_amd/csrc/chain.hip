@@ -1,5 +1,7 @@
 // chain.hip -- host side of the persistent reverse-chain kernel (chain.h): eligibility, workspace, launch, status.
 #include <stdlib.h>
+#include <time.h>
+#include <unistd.h>
 #include <algorithm>
 #include <vector>
 #include "chain.h"
@@ -72,18 +74,69 @@ static int ensure_buf(float** p, int64_t* cap, int64_t floats, hipStream_t s) {
   return OSD_OK;
 }
 
+// Waits for the chain launched last and reads its status word into *st.  The wait is a hipStreamQuery poll with a wall-clock
+// budget (10 x the estimated run time + 2 s, or osd_set_option("chain_wall_budget_ms")): the in-kernel spin budget cannot see a
+// workgroup that is stuck at a barrier, and a blind hipStreamSynchronize would then block the caller forever.  On expiry the
+// host raises CHAIN_ABORT in the status word through a second stream -- every dependency wait and every unit boundary checks
+// that word, so a kernel whose workgroups are merely waiting drains within microseconds -- and gives the device a grace period;
+// OSD_EHIP only if the kernel still does not end (the stream is then unusable and the message says so).
+static int chain_wait_status(osd_handle* h, unsigned* st) {
+  *st = CHAIN_OK;
+  if (!h->chain_pending || !h->chain_sync) return OSD_OK;
+  hipStream_t s = h->stream;
+  const double budget_ms = h->chain_wall_budget_ms > 0 ? (double)h->chain_wall_budget_ms : 10.0 * h->chain_expected_ms + 2000.0;
+  auto now_ms = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec; };
+  auto poll = [&](double limit_ms) -> hipError_t {
+    const double t0 = now_ms();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(s);
+      if (e != hipErrorNotReady) return e;
+      const double el = now_ms() - t0;
+      if (el > limit_ms) return hipErrorNotReady;
+      if (el > 2.0) usleep(el > 100.0 ? 1000 : 100);      // short chains: spin; long ones: sleep between polls
+    }
+  };
+  hipError_t e = poll(budget_ms);
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();
+    if (!h->abort_stream) OSD_HIP(hipStreamCreateWithFlags(&h->abort_stream, hipStreamNonBlocking));
+    static const unsigned abort_word = CHAIN_ABORT;
+    OSD_HIP(hipMemcpyAsync(h->chain_sync, &abort_word, 4, hipMemcpyHostToDevice, h->abort_stream));
+    OSD_HIP(hipStreamSynchronize(h->abort_stream));
+    e = poll(std::max(5000.0, 0.25 * budget_ms));
+    if (e == hipErrorNotReady) {
+      (void)hipGetLastError();
+      set_error("the reverse-chain kernel did not finish within %.0f ms and did not react to the abort flag (a workgroup is stuck outside a "
+                "dependency wait); the handle's stream is blocked -- destroy the process's HIP context", budget_ms);
+      return OSD_EHIP;
+    }
+  }
+  OSD_HIP(e);
+  OSD_HIP(hipMemcpyAsync(st, h->chain_sync, 4, hipMemcpyDeviceToHost, s));
+  OSD_HIP(hipStreamSynchronize(s));
+  h->chain_pending = false;
+  return OSD_OK;
+}
+
 // Blocks until the previous chain's status word is known; OSD_EHIP if that chain gave up in a dependency wait.
 int chain_check_status(osd_handle* h) {
-  if (!h->chain_pending || !h->chain_sync) return OSD_OK;
-  unsigned st = 0;
-  OSD_HIP(hipMemcpyAsync(&st, h->chain_sync, 4, hipMemcpyDeviceToHost, h->stream));
-  OSD_HIP(hipStreamSynchronize(h->stream));
-  h->chain_pending = false;
+  unsigned st = CHAIN_OK;
+  OSD_TRY(chain_wait_status(h, &st));
   if (st != CHAIN_OK) {
-    set_error("the reverse-chain kernel gave up waiting for a row tile of an earlier step (status %u): its results are invalid; "
-              "the workgroups were probably not all resident -- retry with osd_set_option(\"sampler\", 2)", st);
+    set_error("the reverse-chain kernel gave up waiting for a row tile of an earlier step (status %u: %s): its results are invalid; "
+              "call osd_sample_chain with OSD_F_SYNC to have such a chain re-run on the per-layer kernels, or osd_set_option(\"sampler\", 2)",
+              st, st == CHAIN_ABORT ? "host wall-clock budget" : "in-kernel spin budget");
     return OSD_EHIP;
   }
+  return OSD_OK;
+}
+
+// Synchronous variant for osd_sample_chain(OSD_F_SYNC): *gave_up = 1 when the chain's results are invalid (the caller re-runs
+// the chain on the per-layer kernels), errors only for HIP failures and a device that does not come back.
+int chain_finish(osd_handle* h, int* gave_up) {
+  unsigned st = CHAIN_OK;
+  OSD_TRY(chain_wait_status(h, &st));
+  *gave_up = st != CHAIN_OK;
   return OSD_OK;
 }
 
@@ -98,8 +151,10 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
   if (max_grid < 1) { set_error("the chain kernel does not fit this device"); return OSD_EUNSUPPORTED; }
   const int BP = ChainTile::BP;
   const int n_tiles = (int)((n + BP - 1) / BP);
+  // chain_grid > 0 sets the workgroup count (tests): below the tile count it forces every hand-off across workgroups, above it
+  // the surplus workgroups start on later steps of a tile and wait for the earlier ones
   int grid = std::min(n_tiles, max_grid);
-  if (h->chain_grid > 0) grid = std::min(grid, h->chain_grid);
+  if (h->chain_grid > 0) grid = (int)std::min<int64_t>(std::min(h->chain_grid, max_grid), (int64_t)n_tiles * T);
 
   // ---- per-slot activation workspace.  Buffers: h0, and (mid, out) of every block, each [128][C]; a buffer is live from the
   // layer that writes it to the last layer that reads it (block outputs of the encoder live on until their decoder block pops
@@ -167,7 +222,7 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
   ca.progress = h->chain_sync + 4 + 2048;
   ca.stagger = h->chain_stagger;
   ca.stamps = h->chain_stamps;
-  ca.spin_budget = 500000000ull;            // 5 s of s_memrealtime ticks: a unit takes milliseconds
+  ca.spin_budget = h->chain_spin_budget;    // default 5 s of s_memrealtime ticks: a unit takes milliseconds
 
   // ---- layer table ----
   const ParamMap& pm = a.pm;
@@ -247,6 +302,16 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
     OSD_HIP(hipGetLastError());
   }
   h->chain_pending = true;
+  // run-time estimate for the host's wall-clock budget: a unit (128 rows through every layer) runs at ~0.24 TFLOP/s per
+  // resident workgroup when two share a CU (2.8 ms at the BASELINE shape)
+  {
+    double flop_row = 0;
+    for (int l = 0; l < nl; ++l) flop_row += 2.0 * ca.L[l].K * ca.L[l].F;
+    const double unit_ms = 128.0 * flop_row / 0.237e12 * 1e3;
+    double rounds = (double)(((int64_t)n_tiles * T + grid - 1) / grid);
+    if (grid >= n_tiles) rounds = std::max(rounds, (double)T);        // the steps of a tile are serial
+    h->chain_expected_ms = rounds * unit_ms;
+  }
   return OSD_OK;
 }
 
@@ -256,6 +321,7 @@ void chain_free(osd_handle* h) {
   if (h->chain_cond) e = hipFree(h->chain_cond);
   if (h->chain_sync) e = hipFree(h->chain_sync);
   if (h->chain_args_dev) e = hipFree(h->chain_args_dev);
+  if (h->abort_stream) { e = hipStreamDestroy(h->abort_stream); h->abort_stream = nullptr; }
   h->chain_args_dev = nullptr;
   free(h->chain_args_host);
   h->chain_args_host = nullptr;

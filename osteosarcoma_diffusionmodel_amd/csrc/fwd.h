@@ -30,6 +30,7 @@ int chain_pick_engine(osd_handle* h, int64_t n, int flags);
 int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, const float* noises, uint64_t seed, int64_t row_offset,
               float* x_out, float* mut_mask_out);
 int chain_check_status(osd_handle* h);
+int chain_finish(osd_handle* h, int* gave_up);
 void chain_free(osd_handle* h);
 // wgrad_group.hip
 struct WgPending;

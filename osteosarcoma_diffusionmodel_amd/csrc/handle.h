@@ -104,8 +104,7 @@ struct osd_handle {
   float* loss_dev = nullptr;
   int* t_san = nullptr;              // clamped copy of a caller-supplied t_index (sanitize_t)
   int64_t t_san_cap = 0;
-  double* normsq_dev = nullptr;
-  int64_t last_adam_step = 0;
+  double* normsq_dev = nullptr;      // 256 per-workgroup partials of the gradient norm (osd_clip_adamw_step)
   // weight-gradient side stream of the backward pass and its fork/join events
   hipStream_t wgrad_stream = nullptr;
   std::vector<hipEvent_t> ev_pool;
@@ -131,6 +130,11 @@ struct osd_handle {
   void* chain_args_host = nullptr;   // host copies of the same (kept alive while their uploads may be pending)
   int chain_args_cap = 0;
   bool chain_pending = false;        // a chain was launched whose status word has not been read yet
+  unsigned long long chain_spin_budget = 500000000ull;   // osd_set_option("chain_spin_budget"): s_memrealtime ticks (100 MHz) a dependency wait may take (5 s)
+  int64_t chain_wall_budget_ms = 0;  // osd_set_option("chain_wall_budget_ms"): host-side budget of a synchronous chain; 0 = 10 x the expected run time + 2 s
+  double chain_expected_ms = 0.0;    // run-time estimate of the chain launched last (chain_run)
+  int64_t chain_fallbacks = 0;       // chains that gave up and were re-run on the per-layer kernels (osd_get_option)
+  hipStream_t abort_stream = nullptr;   // carries the host's abort flag to a chain kernel that overran its wall-clock budget
   unsigned long long* chain_stamps = nullptr;   // diagnostic builds (csrc/diag): device buffer of 8 counters per workgroup, else null
   int last_engine = 0;               // engine of the most recent osd_sample_chain (0 per-layer, 1 chain kernel)
   // osd_profile_step: when non-null, run_trunk records prof_events[prof_i++] after every launch

@@ -360,9 +360,12 @@ hipError_t launch_small_wgrad(hipStream_t s, const float* x, int kin, const floa
 }
 
 // ---- clip_grad_norm_ + AdamW over flat buffers -----------------------------------------------
-// One double atomic per workgroup: on one address they serialise in L2 (~100 ns each), so the grid is one workgroup per CU
-// (256 atomics), each thread streaming float4s, not one workgroup per 2048 elements (1 300 atomics = most of the old 20 us).
-__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int64_t n, double* out) {
+// Global L2 norm without atomics and without state: k_sumsq leaves one double per workgroup (at most 256, one workgroup per
+// CU, each thread streaming float4s) and every workgroup of k_adamw adds those partials up again in a fixed order (2 KB from
+// L2).  Deterministic, no accumulator to zero, nothing that depends on the previous call (r2: two atomically accumulated sums
+// alternating with the step's parity -- a repeated or skipped step found a dirty accumulator).
+constexpr int NORM_PARTS = 256;
+__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int64_t n, double* parts) {
   double s = 0.0;
   const int64_t n4 = (reinterpret_cast<uintptr_t>(g) & 15) == 0 ? n >> 2 : 0;
   const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -380,44 +383,65 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int6
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) part[w] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) parts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-// normsq_next: the accumulator the NEXT step's k_sumsq will add into, zeroed here (nobody touches it during this launch), so the
-// norm needs no memset launch of its own
-__global__ void k_adamw(float* p, float* g, float* m, float* v, int64_t n, AdamArgs a, const double* normsq, double* normsq_next, float* norm_out) {
+__device__ __forceinline__ void adamw_one(float& pi, float& gi, float& mi, float& vi, const AdamArgs& a, float coef) {
+  if (a.max_norm > 0.f) gi = __fmul_rn(gi, coef);                       // clip_grad_norm_ scales the grads in place
+  pi = __fmul_rn(pi, a.decay);                                          // p.mul_(1 - lr*wd)
+  mi = __fadd_rn(mi, __fmul_rn(a.one_minus_b1, __fsub_rn(gi, mi)));     // exp_avg.lerp_(g, 1-b1)
+  vi = __fmul_rn(vi, a.b2);
+  vi = __fadd_rn(vi, __fmul_rn(__fmul_rn(a.one_minus_b2, gi), gi));     // mul_(b2).addcmul_(g, g, 1-b2)
+  const float denom = __fadd_rn(__fdiv_rn(sqrtf(vi), a.bc2_sqrt), a.eps);
+  pi = __fadd_rn(pi, __fmul_rn(a.neg_step_size, __fdiv_rn(mi, denom)));   // addcdiv_(m, denom, -lr/bc1)
+}
+// HBM-bound: 7 streams of n floats (read p, g, m, v; write p, m, v; g is written back only when clipping is on).  16-byte
+// accesses when the four arrays are 16-byte aligned (flat parameter buffers are), scalar tail / fallback otherwise.
+__global__ __launch_bounds__(256) void k_adamw(float* p, float* g, float* m, float* v, int64_t n, AdamArgs a, const double* parts, int nparts,
+                                               float* norm_out) {
+  __shared__ double sh[4];
+  {
+    double s = (int)threadIdx.x < nparts ? parts[threadIdx.x] : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+  }
   float coef = 1.0f;
-  const float norm = (float)sqrt(*normsq);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *normsq_next = 0.0;
+  const float norm = (float)sqrt((sh[0] + sh[1]) + (sh[2] + sh[3]));
   if (a.max_norm > 0.f) {
     coef = a.max_norm / (norm + 1e-6f);
     if (coef > 1.0f) coef = 1.0f;
   }
   if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = norm;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float gi = g[i];
-    if (a.max_norm > 0.f) { gi = __fmul_rn(gi, coef); g[i] = gi; }     // clip_grad_norm_ scales the grads in place
-    float pi = __fmul_rn(p[i], a.decay);                                 // p.mul_(1 - lr*wd)
-    float mi = m[i];
-    mi = __fadd_rn(mi, __fmul_rn(a.one_minus_b1, __fsub_rn(gi, mi)));    // exp_avg.lerp_(g, 1-b1)
-    float vi = __fmul_rn(v[i], a.b2);
-    vi = __fadd_rn(vi, __fmul_rn(__fmul_rn(a.one_minus_b2, gi), gi));    // mul_(b2).addcmul_(g, g, 1-b2)
-    const float denom = __fadd_rn(__fdiv_rn(sqrtf(vi), a.bc2_sqrt), a.eps);
-    pi = __fadd_rn(pi, __fmul_rn(a.neg_step_size, __fdiv_rn(mi, denom)));   // addcdiv_(m, denom, -lr/bc1)
+  const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  const int64_t n4 = al ? n >> 2 : 0;
+  float4* p4 = reinterpret_cast<float4*>(p); float4* g4 = reinterpret_cast<float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pi = p4[i], gi = g4[i], mi = m4[i], vi = v4[i];
+    adamw_one(pi.x, gi.x, mi.x, vi.x, a, coef);
+    adamw_one(pi.y, gi.y, mi.y, vi.y, a, coef);
+    adamw_one(pi.z, gi.z, mi.z, vi.z, a, coef);
+    adamw_one(pi.w, gi.w, mi.w, vi.w, a, coef);
+    if (a.max_norm > 0.f) g4[i] = gi;
+    p4[i] = pi; m4[i] = mi; v4[i] = vi;
+  }
+  for (int64_t i = 4 * n4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float pi = p[i], gi = g[i], mi = m[i], vi = v[i];
+    adamw_one(pi, gi, mi, vi, a, coef);
+    if (a.max_norm > 0.f) g[i] = gi;
     p[i] = pi; m[i] = mi; v[i] = vi;
   }
 }
 
-hipError_t launch_clip_adamw(hipStream_t s, float* p, float* g, float* m, float* v, int64_t n, const AdamArgs& a, double* normsq_ws,
-                             int64_t step, float* norm_out) {
+// norm_ws: device scratch of NORM_PARTS (256) doubles, no initial state required
+hipError_t launch_clip_adamw(hipStream_t s, float* p, float* g, float* m, float* v, int64_t n, const AdamArgs& a, double* norm_ws, float* norm_out) {
   if (n <= 0) return hipSuccess;
-  // two accumulators used in turn (normsq_ws[step & 1]); both start at zero (the owner zeroes the workspace once)
-  double* cur = normsq_ws + (step & 1);
-  double* nxt = normsq_ws + ((step + 1) & 1);
   int grid = ew_grid(n, 256 * 8);
-  if (grid > 256) grid = 256;
-  hipLaunchKernelGGL(k_sumsq, grid, 256, 0, s, g, n, cur);
-  hipLaunchKernelGGL(k_adamw, ew_grid(n, 256 * 4), 256, 0, s, p, g, m, v, n, a, cur, nxt, norm_out);
+  if (grid > NORM_PARTS) grid = NORM_PARTS;
+  hipLaunchKernelGGL(k_sumsq, grid, 256, 0, s, g, n, norm_ws);
+  hipLaunchKernelGGL(k_adamw, ew_grid(n, 256 * 4), 256, 0, s, p, g, m, v, n, a, norm_ws, grid, norm_out);      // one float4 per thread
   return hipGetLastError();
 }
 

@@ -58,7 +58,6 @@ struct AdamArgs {
   float bc2_sqrt, eps, neg_step_size;
   float max_norm;
 };
-hipError_t launch_clip_adamw(hipStream_t s, float* p, float* g, float* m, float* v, int64_t n, const AdamArgs& a, double* normsq_ws,
-                             int64_t step, float* norm_out);
+hipError_t launch_clip_adamw(hipStream_t s, float* p, float* g, float* m, float* v, int64_t n, const AdamArgs& a, double* norm_ws, float* norm_out);
 
 }  // namespace osd

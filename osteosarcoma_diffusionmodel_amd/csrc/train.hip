@@ -190,6 +190,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   std::vector<WgPending> pend;
   std::vector<WgPending>* grp = h->grouped_wgrad ? &pend : nullptr;
   int ev = 0, ev_closed = 0, n_flush = 0;
+  bool s2_slabs_busy = false;          // an immediate split-K weight gradient on the side stream may still be using W.slabs
   auto record = [&]() -> int {        // bucket complete up to the pending weight gradients
     ++ev_closed;
     if (!grp) { if (events) OSD_HIP(hipEventRecord((hipEvent_t)events[ev], s2)); ++ev; }
@@ -210,6 +211,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     }
     OSD_TRY(fork());
     OSD_HIP(wgrad(s2, W, x, ldx, kin, gz, ldg, nout, rows, dw, lddw, b0));
+    if (!small && s2 != s) s2_slabs_busy = true;
     if (b0 && !small) OSD_HIP(launch_colsum(s2, gz, ldg, rows, nout, b0));
     if (b0 && small && (b1 || b2)) { set_error("internal: shared bias on the small weight-gradient path"); return OSD_EINVAL; }
     if (b0 && !small)
@@ -263,6 +265,13 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     if (s2 != s) {
       if (!cols.empty()) { OSD_TRY(fork()); OSD_TRY(side_leaves(s2)); }
       if (mid_done) OSD_HIP(hipStreamWaitEvent(s, mid_done, 0));     // slab workspace handed back by the mid-pass flush
+      if (s2_slabs_busy && grp && !pend.empty()) {                    // ... and by immediate split-K weight gradients (e.g. the
+        hipEvent_t e;                                                 // ConditionalEmbedding's first Linear at cond_dim 8 or 12)
+        OSD_TRY(next_event(&e));
+        OSD_HIP(hipEventRecord(e, s2));
+        OSD_HIP(hipStreamWaitEvent(s, e, 0));
+        s2_slabs_busy = false;
+      }
     } else {
       OSD_TRY(side_leaves(s));
     }
@@ -566,7 +575,7 @@ int osd_get_loss_parts(osd_handle* h, float* parts_host3) {
   return OSD_OK;
 }
 
-static int clip_adamw(hipStream_t stream, double* normsq_ws, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+static int clip_adamw(hipStream_t stream, double* norm_ws, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
                       double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm, int64_t step, float* grad_norm_out) {
   AdamArgs a{};
   const double bc1 = 1.0 - pow(beta1, (double)step);
@@ -579,7 +588,7 @@ static int clip_adamw(hipStream_t stream, double* normsq_ws, float* param, float
   a.eps = (float)eps;
   a.neg_step_size = (float)(-(lr / bc1));
   a.max_norm = (float)max_norm;
-  OSD_HIP(launch_clip_adamw(stream, param, grad, exp_avg, exp_avg_sq, numel, a, normsq_ws, step, grad_norm_out));
+  OSD_HIP(launch_clip_adamw(stream, param, grad, exp_avg, exp_avg_sq, numel, a, norm_ws, grad_norm_out));
   return OSD_OK;
 }
 
@@ -588,11 +597,7 @@ int osd_clip_adamw_step(osd_handle* h, float* param, float* grad, float* exp_avg
   if (!h || !param || !grad || !exp_avg || !exp_avg_sq) { set_error("null argument"); return OSD_EINVAL; }
   if (numel <= 0 || step < 1) { set_error("numel and step must be positive"); return OSD_EINVAL; }
   OSD_HIP(hipSetDevice(h->cfg.device));
-  if (!h->normsq_dev) { OSD_HIP(hipMalloc((void**)&h->normsq_dev, 64)); OSD_HIP(hipMemset(h->normsq_dev, 0, 64)); h->last_adam_step = 0; }
-  // the two norm accumulators alternate with the step's parity and each launch zeroes the next one: a step that does not
-  // follow the previous one (resume, replay) finds its accumulator in an unknown state
-  if (step != h->last_adam_step + 1) OSD_HIP(hipMemsetAsync(h->normsq_dev, 0, 64, h->stream));
-  h->last_adam_step = step;
+  if (!h->normsq_dev) OSD_HIP(hipMalloc((void**)&h->normsq_dev, 256 * sizeof(double)));
   return clip_adamw(h->stream, h->normsq_dev, param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, max_norm, step,
                     grad_norm_out);
 }

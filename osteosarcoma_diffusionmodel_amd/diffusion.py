@@ -232,9 +232,11 @@ class BiologyAwareDiffusionModel(nn.Module):
         # reverse-chain engine: "auto" (library default: the persistent chain kernel for large eval-mode batches of a
         # 256/512-wide architecture, else the per-layer kernels), "chain", "graph" (per-layer kernels; hipGraph iff use_graph)
         self.sampler: str = "auto"
-        self.chain_grid: Optional[int] = None             # cap on the chain kernel's workgroups (tests)
+        self.chain_grid: Optional[int] = None             # workgroup count of the chain kernel (tests)
         self.chain_steps_per_launch: Optional[int] = None
         self.chain_stagger: Optional[int] = None
+        self.chain_spin_budget: Optional[int] = None      # ticks (100 MHz) a dependency wait inside the chain kernel may take
+        self.chain_wall_budget_ms: Optional[int] = None   # host-side budget of a chain (0 / None: 10 x the estimate + 2 s)
         self.last_sampler: Optional[str] = None           # engine the most recent sample() ran on
         self.train_streams: Optional[int] = None      # 1 = whole backward on one stream, 2 (library default) = weight gradients on a side stream
         # optional constraint losses (set_constraints); None = the reference's eps-MSE only
@@ -334,7 +336,8 @@ class BiologyAwareDiffusionModel(nn.Module):
             raise ValueError(f"sampler must be 'auto', 'chain' or 'graph', got {self.sampler!r}")
         L.check(L.lib().osd_set_option(eng.handle, b"sampler", mode))
         for name, val in (("chain_grid", self.chain_grid), ("chain_steps_per_launch", self.chain_steps_per_launch),
-                          ("chain_stagger", self.chain_stagger)):
+                          ("chain_stagger", self.chain_stagger), ("chain_spin_budget", self.chain_spin_budget),
+                          ("chain_wall_budget_ms", self.chain_wall_budget_ms)):
             if val is not None:
                 L.check(L.lib().osd_set_option(eng.handle, name.encode(), int(val)))
         return eng
@@ -461,12 +464,22 @@ class BiologyAwareDiffusionModel(nn.Module):
         if seed is None:
             seed = _draw_seed()
         flags = self._flags() | (L.OSD_F_GRAPH if self.use_graph else 0)
-        chain = L.lib().osd_sample_engine(eng.handle, n, flags) == 1
-        self.last_sampler = "chain" if chain else "graph"
-        if chain:
-            flags |= L.OSD_F_SYNC       # the chain kernel's bounded waits report through a status word: read it before returning
+        engine = L.lib().osd_sample_engine(eng.handle, n, flags)
+        if engine < 0:
+            L.check(engine)
+        if engine == 1:
+            # the chain kernel's bounded waits report through a status word: the synchronous call reads it and, should the
+            # chain have given up, re-runs it on the per-layer kernels (same bits) -- sample() cannot fail, as the reference's
+            flags |= L.OSD_F_SYNC
         L.check(L.lib().osd_sample_chain(eng.handle, L.ptr(conditions), n, L.ptr(xT), L.ptr(zs), seed, int(row_offset),
                                          L.ptr(out), L.ptr(mask), flags))
+        used = L.lib().osd_sample_engine(eng.handle, -1, 0)      # the engine that produced the result
+        if used < 0:
+            L.check(used)
+        self.last_sampler = "chain" if used == 1 else "graph"
+        if engine == 1 and used != 1:
+            import warnings
+            warnings.warn(L.last_error() or "the reverse-chain kernel gave up; the chain was re-run on the per-layer kernels")
         if return_mutation_mask:
             return out, mask
         return out

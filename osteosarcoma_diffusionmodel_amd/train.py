@@ -194,7 +194,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.grad_norm = torch.zeros(1, device=flat.flat.device)
-        self._normsq = torch.zeros(8, device=flat.flat.device, dtype=torch.float64)
+        self._normsq = torch.zeros(256, device=flat.flat.device, dtype=torch.float64)     # per-workgroup partials of the gradient norm
         self._step = 0
         for p, o, n in zip(flat.params, flat.offsets[:-1], flat.numels):
             self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.exp_avg[o:o + n].view_as(p),
@@ -241,7 +241,6 @@ class FusedAdamW(torch.optim.Optimizer):
         if len(steps) > 1:
             raise ValueError(f"FusedAdamW steps all parameters together but the loaded state has step counts {sorted(steps)}")
         self._step = steps.pop() if steps else 0
-        self._normsq.zero_()            # the norm accumulators alternate with the step's parity (include/osdiff.h)
         for st in self.state.values():
             st["step"] = torch.tensor(float(self._step))
 

@@ -139,3 +139,78 @@ def test_config3_full_size_engines_agree():
     assert torch.equal(mask_c, mask_g)
     assert set(mask_c.unique().tolist()) <= {0.0, 1.0}
 
+
+
+def _get_option(m, name):
+    import ctypes as C
+    v = C.c_int64(-1)
+    L.check(L.lib().osd_get_option(m._engine().handle, name.encode(), C.byref(v)))
+    return v.value
+
+
+def test_chain_spin_timeout_is_recovered_on_the_per_layer_kernels():
+    """models/diffusion.py:427-449 cannot fail.  One row tile and TWO workgroups: the second workgroup takes step 1 of the tile
+    while the first is still inside step 0, so its dependency wait is certain; a spin budget of one tick (10 ns) makes that
+    wait give up (CHAIN_TIMEOUT).  The synchronous call must notice, re-run the chain on the per-layer kernels from the same
+    x_T / draws and return their result, with a warning instead of an error."""
+    T, n = 12, 128
+    m = _model(T, seed=6)
+    gen = torch.Generator().manual_seed(4)
+    cond = torch.randn(n, 3, generator=gen).cuda()
+    x_T = torch.randn(n, 2000, generator=gen).cuda()
+    ref, ref_mask = _run(m, cond, n, "graph", x_T=x_T, seed=31, row_offset=7)
+    m.sampler, m.chain_grid, m.chain_spin_budget = "chain", 2, 1
+    assert _get_option(m, "chain_fallbacks") == 0
+    with pytest.warns(UserWarning, match="re-run on the per-layer kernels"):
+        out, mask = m.sample(cond, n, x_T=x_T, seed=31, row_offset=7, return_mutation_mask=True)
+    assert m.last_sampler == "graph"
+    assert _get_option(m, "chain_fallbacks") == 1 and _get_option(m, "last_engine") == 0
+    assert torch.equal(out, ref) and torch.equal(mask, ref_mask)
+    # Philox x_T (regenerated from the seed for the second run)
+    ref2, _ = _run(m, cond, n, "graph", seed=32)
+    m.sampler = "chain"
+    with pytest.warns(UserWarning):
+        out2 = m.sample(cond, n, seed=32)
+    assert torch.equal(out2, ref2) and _get_option(m, "chain_fallbacks") == 2
+    # with a sane budget the same geometry (surplus workgroup waiting for its turn) completes on the chain kernel
+    m.chain_spin_budget = 500_000_000
+    out3, _ = _run(m, cond, n, "chain", seed=32)
+    assert torch.equal(out3, ref2) and _get_option(m, "chain_fallbacks") == 2
+
+
+def test_chain_wall_clock_budget_aborts_and_recovers():
+    """The host side of the same guarantee: a synchronous chain is polled (hipStreamQuery) against a wall-clock budget instead
+    of a blind hipStreamSynchronize; on expiry the host raises the abort flag, the workgroups leave at their next unit
+    boundary / dependency poll, and the chain is re-run on the per-layer kernels.  Budget 1 ms against a chain of ~50 ms."""
+    T, n = 40, 20_000
+    m = _model(T, seed=8)
+    cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    ref, ref_mask = _run(m, cond, n, "graph", seed=5)
+    m.sampler, m.chain_wall_budget_ms = "chain", 1
+    with pytest.warns(UserWarning):
+        out, mask = m.sample(cond, n, seed=5, return_mutation_mask=True)
+    assert m.last_sampler == "graph" and _get_option(m, "chain_fallbacks") == 1
+    assert torch.equal(out, ref) and torch.equal(mask, ref_mask)
+    m.chain_wall_budget_ms = 0                  # automatic budget (10 x the estimate + 2 s): the chain kernel finishes
+    out2, _ = _run(m, cond, n, "chain", seed=5)
+    assert torch.equal(out2, ref) and _get_option(m, "chain_fallbacks") == 1
+
+
+def test_chain_timeout_without_sync_is_reported_by_the_next_call():
+    """C ABI without OSD_F_SYNC: the call that launched a chain which gives up returns OSD_OK (nothing is known yet); the next
+    osd_sample_chain on the handle returns OSD_EHIP with the reason; the handle stays usable."""
+    T, n = 6, 128
+    m = _model(T, seed=9)
+    cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    m.sampler, m.chain_grid, m.chain_spin_budget = "chain", 2, 1
+    eng = m._engine()
+    out = torch.empty(n, 2000, device="cuda")
+    args = (eng.handle, L.ptr(cond), n, None, None, 3, 0, L.ptr(out), None)
+    assert L.lib().osd_sample_chain(*args, 0) == L.OSD_OK
+    assert L.lib().osd_sample_chain(*args, 0) == L.OSD_EHIP
+    assert "gave up" in L.last_error()
+    torch.cuda.synchronize()
+    m.chain_spin_budget = 500_000_000
+    ref, _ = _run(m, cond, n, "graph", seed=3)
+    got, _ = _run(m, cond, n, "chain", seed=3)
+    assert torch.equal(got, ref)
