@@ -328,7 +328,7 @@ struct EpiGnBwd {
           const int f = fw + 32 * fb + 8 * q + 4 * h;
           const int g = (fb * 16 + 4 * q) / RPG;
           const int fc = f < F ? f : F - 4;
-          const float2 st = *reinterpret_cast<const float2*>(a.stats + ((size_t)pc * (F / GW) + fc / GW) * 2);
+          const float2 st = ldg2(a.stats + ((size_t)pc * (F / GW) + fc / GW) * 2);
           const float4 z4 = ldq<FAST>(zrow, f, F);
           float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
           if (a.accumulate) add = ldq<FAST>(gyrow, f, F);
@@ -378,7 +378,7 @@ struct EpiGnBwd {
           const int f = fw + 32 * fb + 8 * q + 4 * h;
           const int g = (fb * 16 + 4 * q) / RPG;
           const int fc = f < F ? f : F - 4;
-          const float rstd = a.stats[((size_t)pc * (F / GW) + fc / GW) * 2 + 1];
+          const float rstd = ldg1(a.stats + ((size_t)pc * (F / GW) + fc / GW) * 2 + 1);
           const float4 gv = pre.gamma[fb][q];
           const float gm[4] = {gv.x, gv.y, gv.z, gv.w};
           float o[4];

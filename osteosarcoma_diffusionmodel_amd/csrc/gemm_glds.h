@@ -65,17 +65,6 @@ __device__ __forceinline__ void glds16s(gfloat_ptr sbase, unsigned voff, unsigne
       : "v"(voff), "s"(sbase), "s"(lds_dst)
       : "memory");
 }
-// Explicitly GLOBAL loads / stores for pointers hipcc cannot prove global: fields of an argument block or work list that
-// itself lives in memory (the chain kernel's ChainArgs, the grouped weight-gradient items) are generic pointers, and an access
-// through one is a FLAT instruction -- both counters, out-of-order return (every wait degrades to vmcnt(0) & lgkmcnt(0)), and
-// the LDS pipe takes part in a global access.  Chain kernel, same box: 22.42 k -> 22.80 k patients/s.
-typedef float v4f32 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) v4f32 gfloat4;
-typedef __attribute__((address_space(1))) float gfloat1;
-__device__ __forceinline__ float4 ldg4(const float* p) { const v4f32 v = *(const gfloat4*)p; return make_float4(v.x, v.y, v.z, v.w); }
-__device__ __forceinline__ void stg4(float* p, float4 v) { const v4f32 w = {v.x, v.y, v.z, v.w}; *(gfloat4*)p = w; }
-__device__ __forceinline__ void stg1(float* p, float v) { *(gfloat1*)p = v; }
-
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }

@@ -38,17 +38,13 @@ struct WgReduce {
 constexpr int WG_BK = 32;
 constexpr int WG_LDS_BYTES = 2 * 2 * WG_BK * 128 * 4;     // two stages of (A, B) [32][128] fp32
 
-// A workgroup runs items blockIdx.x, blockIdx.x + gridDim.x, ...: one item each when the grid covers the list, or a walk
-// over it when the host caps the grid (to leave CU slots to a concurrent stream).
-__global__ __launch_bounds__(NTHREADS, 2) void wgrad_group_kernel(const WgItem* __restrict__ items, int n_items) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// One work item with all 256 threads of the workgroup; smem = WG_LDS_BYTES.  Ends with a barrier (the staging buffers are free).
+__device__ __forceinline__ void wgrad_item(const WgItem& it, float* smem) {
   constexpr int TILE = WG_BK * 128;
   float* As0 = smem;
   float* As1 = smem + TILE;
   float* Bs0 = smem + 2 * TILE;
   float* Bs1 = smem + 3 * TILE;
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-  const WgItem it = items[item];            // by value: the DMA asm statements clobber "memory"
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -120,7 +116,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_group_kernel(const WgItem* 
     if (n < it.P) {
 #pragma unroll
       for (int i = 0; i < 3; ++i)
-        if (it.bias[i]) atomicAdd(it.bias[i] + n, csum);
+        if (it.bias[i]) __hip_atomic_fetch_add((gfloat1*)(it.bias[i] + n), csum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
@@ -137,25 +133,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_group_kernel(const WgItem* 
           stg4(it.out + (size_t)p * it.ldo + f, make_float4(acc[fb][pb][4 * q], acc[fb][pb][4 * q + 1], acc[fb][pb][4 * q + 2], acc[fb][pb][4 * q + 3]));
       }
   __syncthreads();                          // the next item restages buffer 0
-  }
 }
 
-// out[p][f] = sum over slices (fixed order) of the dense slabs; one grid row per tensor
-__global__ void wgrad_group_reduce(const WgReduce* __restrict__ items) {
-  const WgReduce& r = items[blockIdx.y];
-  const int c4n = r.F >> 2;
-  const long long total = (long long)r.P * c4n;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int p = (int)(i / c4n);
-    const int c = 4 * (int)(i - (long long)p * c4n);
-    const float* s = r.slab + (size_t)p * r.F + c;
-    float4 acc = *reinterpret_cast<const float4*>(s);
-    for (int k = 1; k < r.n_slices; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(s + (size_t)k * r.stride);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    *reinterpret_cast<float4*>(r.out + (size_t)p * r.ldo + c) = acc;
-  }
-}
+// wgrad_group.hip: a workgroup runs items blockIdx.x, blockIdx.x + gridDim.x, ...; out[p][f] = sum over slices (fixed order)
+__global__ void wgrad_group_kernel(const WgItem* __restrict__ items, int n_items);
+__global__ void wgrad_group_reduce(const WgReduce* __restrict__ items);
 
 }  // namespace osd

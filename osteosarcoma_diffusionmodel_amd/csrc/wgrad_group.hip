@@ -8,6 +8,34 @@
 
 namespace osd {
 
+// A workgroup runs items blockIdx.x, blockIdx.x + gridDim.x, ...: one item each when the grid covers the list, or a walk
+// over it when the host caps the grid (to leave CU slots to a concurrent stream).
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_group_kernel(const WgItem* __restrict__ items, int n_items) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const WgItem it = items[item];            // by value: the DMA asm statements clobber "memory"
+    wgrad_item(it, smem);
+  }
+}
+
+// out[p][f] = sum over slices (fixed order) of the dense slabs; one grid row per tensor
+__global__ void wgrad_group_reduce(const WgReduce* __restrict__ items) {
+  const WgReduce& r = items[blockIdx.y];
+  const int c4n = r.F >> 2;
+  const long long total = (long long)r.P * c4n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i / c4n);
+    const int c = 4 * (int)(i - (long long)p * c4n);
+    const float* s = r.slab + (size_t)p * r.F + c;
+    float4 acc = *reinterpret_cast<const float4*>(s);
+    for (int k = 1; k < r.n_slices; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(s + (size_t)k * r.stride);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(r.out + (size_t)p * r.ldo + c) = acc;
+  }
+}
+
 static bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 bool wgrad_group_ok(const WgPending& w) {
