@@ -68,6 +68,8 @@ def parse_args():
     ap.add_argument("--profile-rows", type=int, default=0, help="rows for the per-kernel event timing (default: chunk)")
     ap.add_argument("--profile-only", action="store_true", help="run only the per-kernel roofline leg (for rocprofv3 --stats)")
     ap.add_argument("--train-only", action="store_true", help="run only the training leg (for rocprofv3 --stats)")
+    ap.add_argument("--no-reference-workload", action="store_true", help="skip the reference's default generation workload leg")
+    ap.add_argument("--reference-workload-only", action="store_true")
     return ap.parse_args()
 
 
@@ -168,6 +170,45 @@ def cpu_baseline(state_dict, full_sample=True, budget_s=12.0):
 
 
 # ------------------------------------------------------------------------------------------------
+# the reference's own default generation workload (config/config.yaml:119-141, main.py:227-230, QUICKSTART.md:202)
+# ------------------------------------------------------------------------------------------------
+def reference_workload_leg(dev):
+    """SyntheticPatientGenerator.generate_scenarios over the three config.yaml scenarios, T = 1000, at the reference's real
+    TARGET-OS dims (62 mutations + 5054 expression genes + 26 pathways = 5142 features, D % 4 == 2) and at the BASELINE dims
+    (50 + 1900 + 50): 1000 patients per scenario (utils/generate.py:146-175) and main.py's default split of
+    generation.num_synthetic_samples = 1000 over the scenarios (333 each).  Wall time of the whole call, i.e. including the
+    device-to-host copy and the numpy split of utils/generate.py:127-135.  QUICKSTART.md:202 quotes "5 min" GPU / "10 min" CPU
+    for 1000 patients at the real dims on unspecified hardware (~3.3 / ~1.7 patients/s)."""
+    import torch
+    from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel, SyntheticPatientGenerator
+    scen = [{"name": n, "conditions": c} for n, c in zip(("early_stage_good_prognosis", "metastatic_poor_prognosis", "typical_patient"), SCENARIOS)]
+    out = {"quickstart_reference": {"patients_per_s_gpu": 3.3, "patients_per_s_cpu": 1.7,
+                                    "source": "QUICKSTART.md:202 (1000 patients, dims 62/5054/26, unspecified hardware)"}, "runs": []}
+    for dims in ((62, 5054, 26), (50, 1900, 50)):
+        torch.manual_seed(0)
+        model = BiologyAwareDiffusionModel(*dims, 3, CONF).to(dev).eval()
+        gen = SyntheticPatientGenerator(model, CONF, device=dev)
+        D = sum(dims)
+        flop_row_step = 2 * (2 * D * 256 + 1_572_864)                # input_proj + trunk + output_proj, hidden [256, 512, 256]
+        gen.generate(128, scen[0]["conditions"])                    # warm-up: kernel loading, workspace, graph capture
+        torch.cuda.synchronize()
+        for per in (1000, 333):
+            t0 = time.perf_counter()
+            res = gen.generate_scenarios(scen, per)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert all(r["expression"].shape == (per, dims[1]) for r in res.values())
+            n = per * len(scen)
+            out["runs"].append({"dims": list(dims), "D": D, "patients_per_scenario": per, "patients": n, "T": 1000,
+                                "seconds": round(dt, 4), "patients_per_s": round(n / dt, 1), "engine": model.last_sampler,
+                                "achieved_tflops": round(n * 1000 * flop_row_step / dt / 1e12, 2),
+                                "frac_of_fp32_mfma_peak": round(n * 1000 * flop_row_step / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                "vs_quickstart_gpu": round(n / dt / 3.3, 1)})
+        del model, gen
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # training leg (BASELINE config 2 / 4)
 # ------------------------------------------------------------------------------------------------
 def train_leg(dev, dist, world, rank, steps, backend):
@@ -260,7 +301,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    rccl_ranks = 1
+    comm_ranks = 1
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -269,7 +310,7 @@ def main():
             dist.init_process_group(backend)
         ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())
+        comm_ranks = int(ones.item())
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel, _lib as L
@@ -302,6 +343,10 @@ def main():
         torch.cuda.synchronize()
 
     line = {}
+    if args.reference_workload_only:
+        if rank == 0:
+            print(json.dumps({"reference_workload": reference_workload_leg(dev)}), flush=True)
+        return
     if args.train_only:
         tr = train_leg(dev, dist, world, rank, args.train_steps, backend)
         if rank == 0:
@@ -344,6 +389,9 @@ def main():
     train = None
     if not args.no_train and not args.profile_only:
         train = train_leg(dev, dist, world, rank, args.train_steps, backend)
+    refw = None
+    if rank == 0 and world == 1 and not args.no_reference_workload and not args.profile_only:
+        refw = reference_workload_leg(dev)
     if rank == 0 and not args.no_cpu_baseline and world == 1 and not args.profile_only:
         cpu = cpu_baseline(model.state_dict(), full_sample=not args.no_cpu_full_sample)   # N = 1 only (one host, one CPU timing)
 
@@ -358,10 +406,11 @@ def main():
                        "parallelism": f"patients sharded over {world} GPU(s), no collective",
                        "sampler": engine_used, "chunk_rows": model.sample_chunk_rows or 65536, "streams": model.sample_streams or 2,
                        "graph": model.use_graph},
-            "rccl_ranks": rccl_ranks, "comm_backend": None if world == 1 else backend,
+            "comm_ranks": comm_ranks, "comm_backend": None if world == 1 else backend,
+            "rccl_ranks": comm_ranks if (world > 1 and backend == "nccl") else None,       # only when the all-reduce really ran over RCCL
             "achieved_tflops_end_to_end": round(value * 1000 * FLOP_PER_PATIENT_STEP / 1e12 / world, 2),
             "frac_of_fp32_mfma_peak_end_to_end": round(value * 1000 * FLOP_PER_PATIENT_STEP / 1e12 / world / FP32_MFMA_PEAK_TFLOPS, 4),
-            "roofline": roof, "train": train, "cpu_baseline": cpu,
+            "roofline": roof, "train": train, "reference_workload": refw, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -163,10 +163,18 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
   const int n = (int)in.n;
   {
     GemmArgs g{};
-    g.A = h->w_in_packed; g.lda = h->w_in_ld; g.B0 = in.x; g.ldb0 = in.ldx; g.K0 = a.D;
-    g.F = a.H0; g.P = n; g.K = a.D;
+    const int kx = in.kx > 0 ? in.kx : a.D;
+    g.A = h->w_in_packed; g.lda = h->w_in_ld; g.B0 = in.x; g.ldb0 = in.ldx; g.K0 = kx;
+    g.F = a.H0; g.P = n; g.K = kx;
     EpiInput::Args ea{h->params[pm.in_b], h->d_temb, a.H0, in.t_index, in.t_dev, in.t_imm, ws.cproj, a.H0, ws.h0, a.H0};
-    OSD_HIP(launch_input(s, g, ea, true));
+    bool done = false;
+    if (in.in_slices > 1 && in.in_slabs) {
+      const hipError_t e = launch_input_splitk(s, g, ea, in.in_slabs, in.in_slices);
+      if (e == hipSuccess) done = true;
+      else if (e != hipErrorInvalidValue) OSD_HIP(e);
+      else (void)hipGetLastError();
+    }
+    if (!done) OSD_HIP(launch_input(s, g, ea, true));
     OSD_TRY(prof_mark(h, s));
   }
   const float* cur = ws.h0;
@@ -223,16 +231,22 @@ int refresh_derived(osd_handle* h, hipStream_t s) {
   g.F = a.H0; g.P = a.T; g.K = a.time_dim;
   OSD_HIP(launch_linear(s, g, true, true, h->params[a.pm.tp_b], h->d_temb, a.H0, false, false));
   OSD_HIP(launch_copy2d(s, h->params[a.pm.in_w], a.D, h->w_in_packed, h->w_in_ld, a.H0, a.D));   // pad columns stay zero
+  if (h->w_out_packed) {                       // D % 4 != 0: rows [D, Dp) stay zero
+    const size_t hl = (size_t)a.block_out[a.n_blocks - 1];
+    OSD_HIP(hipMemcpyAsync(h->w_out_packed, h->params[a.pm.out_w], (size_t)a.D * hl * 4, hipMemcpyDeviceToDevice, s));
+    OSD_HIP(hipMemcpyAsync(h->b_out_packed, h->params[a.pm.out_b], (size_t)a.D * 4, hipMemcpyDeviceToDevice, s));
+  }
   return OSD_OK;
 }
 
-GemmArgs output_proj_args(osd_handle* h, const FwdWs& ws, int64_t n) {
+// padded: the epilogue works on the padded chain state (Dp columns; the packed weight has zero rows for the pad columns)
+GemmArgs output_proj_args(osd_handle* h, const FwdWs& ws, int64_t n, bool padded) {
   const Arch& a = h->arch;
   const int last = a.n_blocks - 1;
   GemmArgs g{};
-  g.A = h->params[a.pm.out_w]; g.lda = a.block_out[last];
+  g.A = padded ? h->w_out_packed : h->params[a.pm.out_w]; g.lda = a.block_out[last];
   g.B0 = ws.out[last]; g.ldb0 = a.block_out[last]; g.K0 = a.block_out[last];
-  g.F = a.D; g.P = (int)n; g.K = a.block_out[last];
+  g.F = padded ? h->Dp : a.D; g.P = (int)n; g.K = a.block_out[last];
   return g;
 }
 
@@ -309,6 +323,14 @@ static int create_device_state(osd_handle* h) {
   h->w_in_ld = (a.D + BK - 1) / BK * BK;
   OSD_HIP(hipMalloc((void**)&h->w_in_packed, (size_t)a.H0 * h->w_in_ld * 4));
   OSD_HIP(hipMemset(h->w_in_packed, 0, (size_t)a.H0 * h->w_in_ld * 4));
+  h->Dp = (a.D + 3) / 4 * 4;
+  if (h->Dp != a.D) {
+    const size_t hl = (size_t)a.block_out[a.n_blocks - 1];
+    OSD_HIP(hipMalloc((void**)&h->w_out_packed, (size_t)h->Dp * hl * 4));
+    OSD_HIP(hipMemset(h->w_out_packed, 0, (size_t)h->Dp * hl * 4));
+    OSD_HIP(hipMalloc((void**)&h->b_out_packed, (size_t)h->Dp * 4));
+    OSD_HIP(hipMemset(h->b_out_packed, 0, (size_t)h->Dp * 4));
+  }
   OSD_HIP(hipMalloc((void**)&h->main.t_dev, 64));
   OSD_HIP(hipMalloc((void**)&h->loss_dev, 64));
   OSD_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
@@ -361,7 +383,7 @@ int osd_destroy(osd_handle* h) {
   e = hipDeviceSynchronize();
   for (auto& s : h->slots) free_slot(s, true);
   free_slot(h->main, false);
-  float* bufs[] = {h->w_in_packed, h->d_sqrt_ac, h->d_sqrt_1m, h->d_coef, h->d_time_emb, h->d_temb, h->train_arena, h->loss_dev};
+  float* bufs[] = {h->w_in_packed, h->w_out_packed, h->b_out_packed, h->chain_xpad, h->d_sqrt_ac, h->d_sqrt_1m, h->d_coef, h->d_time_emb, h->d_temb, h->train_arena, h->loss_dev};
   for (float* p : bufs) if (p) e = hipFree(p);
   if (h->normsq_dev) e = hipFree(h->normsq_dev);
   if (h->parts_dev) e = hipFree(h->parts_dev);
@@ -404,6 +426,11 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "chain_grid")) {
     if (value < 0 || value > 65536) { set_error("chain_grid must be in [0,65536]"); return OSD_EINVAL; }
     h->chain_grid = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "input_splitk")) {            // per-layer sampling engine: 0 off (default), -1 auto (batches with < 128 input_proj tiles), n slices
+    if (value < -1 || value > 64) { set_error("input_splitk must be in [-1,64]"); return OSD_EINVAL; }
+    h->input_splitk = (int)value;
     return OSD_OK;
   }
   if (!strcmp(name, "chain_spin_budget")) {       // s_memrealtime ticks (100 MHz) a dependency wait inside the chain kernel may take
@@ -467,7 +494,7 @@ int osd_get_option(osd_handle* h, const char* name, int64_t* value) {
       {"chain_steps_per_launch", h->chain_steps_per_launch}, {"chain_stagger", h->chain_stagger},
       {"chain_spin_budget", (int64_t)h->chain_spin_budget}, {"chain_wall_budget_ms", h->chain_wall_budget_ms},
       {"grouped_wgrad", h->grouped_wgrad}, {"fused_gn_bwd", h->fused_gn_bwd}, {"wgrad_mid_flush", h->wgrad_mid_flush},
-      {"train_streams", h->two_stream_bwd ? 2 : 1}, {"persistent_bwd", h->persistent_bwd}, {"bwd_spin_budget", (int64_t)h->bwd_spin_budget},
+      {"input_splitk", h->input_splitk}, {"train_streams", h->two_stream_bwd ? 2 : 1}, {"persistent_bwd", h->persistent_bwd}, {"bwd_spin_budget", (int64_t)h->bwd_spin_budget},
       // read-only counters
       {"chain_fallbacks", h->chain_fallbacks}, {"last_engine", h->last_engine}};
   for (const auto& e : tab)
@@ -610,25 +637,43 @@ static int chain_chunk(osd_handle* h, Slot& sl, const float* cond, int64_t n_tot
   OSD_TRY(release_graph(sl));
   FwdWs ws;
   const int64_t need = carve_fwd(a, nullptr, m, false, &ws);
-  OSD_TRY(ensure_arena(&sl, need));
+  // D % 4 != 0 with device-generated draws: the state of the chunk lives in a padded buffer behind the activations (rows of Dp
+  // floats, pad columns zero at the start) and is copied to the caller's rows at the end; injected draws ([T-1][n][D], rows not
+  // 16-byte aligned) keep the guarded kernels on the caller's tensor
+  const bool padded = h->w_out_packed != nullptr && !noises;
+  const int ldx = padded ? h->Dp : D;
+  const int64_t need_pad = (need + 63) / 64 * 64;
+  // small batches: input_proj split-K (k_fused.hip) -- few output tiles, each a long sequential K loop
+  int in_slices = 0;
+  {
+    const int64_t tiles = (int64_t)((a.H0 + 63) / 64) * ((m + 63) / 64);
+    if (h->input_splitk > 0 && !h->splitk_suspended) in_slices = h->input_splitk;
+    else if (h->input_splitk < 0 && !h->splitk_suspended && ldx >= 1024 && tiles < 128) in_slices = (int)std::min<int64_t>(16, std::max<int64_t>(2, 512 / tiles));
+    in_slices = std::min(in_slices, ldx / 128);
+    if (in_slices < 2) in_slices = 0;
+  }
+  const int64_t x_floats = padded ? (m * (int64_t)ldx + 63) / 64 * 64 : 0;
+  OSD_TRY(ensure_arena(&sl, need_pad + x_floats + (int64_t)in_slices * m * a.H0));
   carve_fwd(a, sl.arena, m, false, &ws);
-  float* x = x_out + r0 * D;                 // the chain state lives in the output rows
+  float* x = padded ? sl.arena + need_pad : x_out + r0 * D;       // else the chain state lives in the output rows
+  float* in_slabs = in_slices ? sl.arena + need_pad + x_floats : nullptr;
+  if (padded) OSD_HIP(hipMemsetAsync(x, 0, (size_t)m * ldx * 4, s));
   const uint32_t roff = (uint32_t)(row_offset + r0);
   const bool train = (flags & OSD_F_TRAIN_MODE) != 0;
   // conditioning is loop-invariant in eval mode (no dropout inside the embedding MLP): hoisted
   OSD_TRY(run_cond(h, s, cond + r0 * a.cond_dim, m, ws));
-  if (x_T) OSD_HIP(launch_copy2d(s, x_T + r0 * D, D, x, D, m, D));
-  else OSD_HIP(launch_fill_randn(s, x, D, m, D, seed, roff, (uint32_t)T, TAG_POSTERIOR));
+  if (x_T) OSD_HIP(launch_copy2d(s, x_T + r0 * D, D, x, ldx, m, D));
+  else OSD_HIP(launch_fill_randn(s, x, ldx, m, D, seed, roff, (uint32_t)T, TAG_POSTERIOR));
   OSD_HIP(launch_set_int(s, sl.t_dev, T - 1));
 
   auto enqueue_step = [&](void) -> int {
     TrunkIn in{};
-    in.x = x; in.ldx = D; in.n = m; in.t_dev = sl.t_dev;
+    in.x = x; in.ldx = ldx; in.kx = ldx; in.n = m; in.t_dev = sl.t_dev; in.in_slabs = in_slabs; in.in_slices = in_slices;
     in.train = train; in.seed = seed; in.row_offset = roff; in.drop_step_dev = sl.t_dev;
     OSD_TRY(run_trunk(h, s, ws, in));
-    GemmArgs g = output_proj_args(h, ws, m);
+    GemmArgs g = output_proj_args(h, ws, m, padded);
     EpiPosterior::Args ea{};
-    ea.bias = h->params[a.pm.out_b]; ea.xin = x; ea.ldx = D; ea.xout = x; ea.ldo = D; ea.coef = h->d_coef;
+    ea.bias = padded ? h->b_out_packed : h->params[a.pm.out_b]; ea.xin = x; ea.ldx = ldx; ea.xout = x; ea.ldo = ldx; ea.coef = h->d_coef;
     ea.t_dev = sl.t_dev; ea.t_imm = 0;
     ea.z = noises ? noises + r0 * D : nullptr; ea.ldzz = D; ea.z_step_stride = (long long)n_total * D; ea.t_first = T - 1;
     ea.seed = seed; ea.row_offset = roff;
@@ -654,6 +699,7 @@ static int chain_chunk(osd_handle* h, Slot& sl, const float* cond, int64_t n_tot
   } else {
     for (int it = 0; it < T; ++it) OSD_TRY(enqueue_step());
   }
+  if (padded) OSD_HIP(launch_copy2d(s, x, ldx, x_out + r0 * D, D, m, D));
   return OSD_OK;
 }
 
@@ -667,6 +713,7 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
   OSD_HIP(hipSetDevice(h->cfg.device));
   OSD_TRY(chain_check_status(h));            // a previous chain-kernel run that gave up is reported here at the latest
   h->last_engine = chain_pick_engine(h, n, flags);
+  if (h->last_engine == 1 && noises && h->w_out_packed) h->last_engine = 0;      // injected draws at D % 4 != 0: guarded per-layer kernels
   bool fell_back = false;
   if (h->last_engine == 1) {
     OSD_TRY(chain_run(h, cond, n, x_T, noises, seed, row_offset, x_out, mut_mask_out));
@@ -683,6 +730,7 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
     ++h->chain_fallbacks;
     h->last_engine = 0;
     fell_back = true;
+    h->splitk_suspended = true;          // the re-run must produce the chain kernel's bits: single-pass input_proj
   }
   // equal chunks (rounded up to whole 128-row tiles) of at most chunk_rows rows
   int64_t n_chunks = (n + h->chunk_rows - 1) / h->chunk_rows;
@@ -712,6 +760,7 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
     if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->slots[i].done, 0);
     if (e != hipSuccess && rc == OSD_OK) { set_error("join failed: %s", hipGetErrorString(e)); rc = OSD_EHIP; }
   }
+  h->splitk_suspended = false;
   if (rc != OSD_OK) return rc;
   if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(h->stream));
   if (fell_back)       // a warning, not an error: osd_last_error() tells what happened, osd_get_option("chain_fallbacks") counts

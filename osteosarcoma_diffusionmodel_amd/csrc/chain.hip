@@ -16,7 +16,7 @@ static int64_t up64(int64_t v) { return (v + 63) / 64 * 64; }
 // The chain kernel covers the 128 x 128 tile with GroupNorm groups of 32 or 64 channels (block widths 256 / 512, the
 // BASELINE shape and its neighbours) in eval mode; everything else runs on the per-layer kernels.
 bool chain_supported(const Arch& a) {
-  if (a.D % 4 || a.H0 % 4) return false;
+  if (a.H0 % 4) return false;              // D % 4 != 0 runs on the padded chain state (handle.h: Dp)
   for (int c : a.block_out)
     if (c != 256 && c != 512) return false;
   if (a.H0 != 256 && a.H0 != 512) return false;
@@ -143,9 +143,15 @@ int chain_finish(osd_handle* h, int* gave_up) {
 int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, const float* noises, uint64_t seed, int64_t row_offset,
               float* x_out, float* mut_mask_out) {
   const Arch& a = h->arch;
-  const int D = a.D, T = a.T, H0 = a.H0;
+  const int T = a.T, H0 = a.H0;
   hipStream_t s = h->stream;
   OSD_TRY(chain_check_status(h));
+  // D % 4 != 0: the kernel works on an internal copy of the state with rows of Dp = roundup(D, 4) floats (pad columns start at
+  // zero, meet zero weights in input_proj and get zero eps from the packed output_proj) and the result is copied out at the end
+  const bool padded = h->w_out_packed != nullptr;
+  if (padded && noises) { set_error("internal: injected draws with D %% 4 != 0 run on the per-layer kernels"); return OSD_EUNSUPPORTED; }
+  const int D = padded ? h->Dp : a.D;
+  float* const x_state = padded ? nullptr : x_out;
   int max_grid = 0;
   OSD_TRY(chain_device_limits(h->cfg.device, &max_grid));
   if (max_grid < 1) { set_error("the chain kernel does not fit this device"); return OSD_EUNSUPPORTED; }
@@ -205,8 +211,14 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
   if (rows_pad > n) OSD_HIP(hipMemsetAsync(cw.cproj + n * H0, 0, (size_t)(rows_pad - n) * H0 * 4, s));
 
   // ---- x_T ----
-  if (x_T) OSD_HIP(launch_copy2d(s, x_T, D, x_out, D, n, D));
-  else OSD_HIP(launch_fill_randn(s, x_out, D, n, D, seed, (uint32_t)row_offset, (uint32_t)T, TAG_POSTERIOR));
+  float* xs = x_state;
+  if (padded) {
+    OSD_TRY(ensure_buf(&h->chain_xpad, &h->chain_xpad_floats, n * (int64_t)D, s));
+    xs = h->chain_xpad;
+    OSD_HIP(hipMemsetAsync(xs, 0, (size_t)n * D * 4, s));
+  }
+  if (x_T) OSD_HIP(launch_copy2d(s, x_T, a.D, xs, D, n, a.D));
+  else OSD_HIP(launch_fill_randn(s, xs, D, n, a.D, seed, (uint32_t)row_offset, (uint32_t)T, TAG_POSTERIOR));
 
   // ---- sync words: [status, queue, pad x2 | cu arrivals x2048 | progress x n_tiles], zeroed before every chain ----
   const int64_t words = 4 + 2048 + ((n_tiles + 3) / 4) * 4;
@@ -255,12 +267,12 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
   }
   {
     ChainLayer& L = ca.L[nl++];
-    L.A = h->params[pm.out_w]; L.lda = cur_w; L.K = cur_w; L.K0 = cur_w; L.F = D;
+    L.A = padded ? h->w_out_packed : h->params[pm.out_w]; L.lda = cur_w; L.K = cur_w; L.K0 = cur_w; L.F = D;
     L.in0 = cur; L.ld0 = cur_w; L.in1 = 0; L.ld1 = 0; L.out = 0; L.ldo = 0; L.kind = CK_POST;
-    L.bias = h->params[pm.out_b]; L.gamma = nullptr; L.beta = nullptr;
+    L.bias = padded ? h->b_out_packed : h->params[pm.out_b]; L.gamma = nullptr; L.beta = nullptr;
   }
   ca.n_layers = nl;
-  ca.x = x_out; ca.D = D; ca.n = (int)n; ca.n_tiles = n_tiles;
+  ca.x = xs; ca.D = D; ca.n = (int)n; ca.n_tiles = n_tiles;
   ca.cproj = cw.cproj; ca.ldc = H0; ca.temb = h->d_temb; ca.ldt = H0; ca.coef = h->d_coef;
   ca.z = noises; ca.ldzz = D; ca.z_step_stride = (long long)n * D; ca.z_t_first = T - 1;
   ca.seed = seed; ca.row_offset = (uint32_t)row_offset;
@@ -301,6 +313,7 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
     hipLaunchKernelGGL(chain_kernel<false>, dim3(grid), dim3(NTHREADS), CHAIN_LDS_BYTES, s, dargs);
     OSD_HIP(hipGetLastError());
   }
+  if (padded) OSD_HIP(launch_copy2d(s, xs, D, x_out, a.D, n, a.D));
   h->chain_pending = true;
   // run-time estimate for the host's wall-clock budget: a unit (128 rows through every layer) runs at ~0.24 TFLOP/s per
   // resident workgroup when two share a CU (2.8 ms at the BASELINE shape)

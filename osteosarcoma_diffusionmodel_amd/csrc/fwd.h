@@ -8,6 +8,8 @@ namespace osd {
 
 struct TrunkIn {
   const float* x; int ldx; int64_t n;
+  float* in_slabs; int in_slices; // > 1: input_proj split-K over that many slices (k_fused.hip), slabs = in_slices x n x H0 floats
+  int kx;                        // K extent of input_proj: 0 = D; Dp when x is the padded chain state (handle.h)
   const int* t_index;            // per-row t (training) or null
   const int* t_dev; int t_imm;   // shared t: device counter (sampling chain) or immediate
   bool train;                    // dropout active
@@ -21,7 +23,7 @@ int64_t carve_fwd(const Arch& a, float* base, int64_t n, bool train, FwdWs* ws);
 int run_cond(osd_handle* h, hipStream_t s, const float* cond, int64_t n, const FwdWs& ws);
 int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in);
 int refresh_derived(osd_handle* h, hipStream_t s);
-GemmArgs output_proj_args(osd_handle* h, const FwdWs& ws, int64_t n);
+GemmArgs output_proj_args(osd_handle* h, const FwdWs& ws, int64_t n, bool padded = false);
 int check_ready(osd_handle* h);
 int check_rows(int64_t n);
 // chain.hip

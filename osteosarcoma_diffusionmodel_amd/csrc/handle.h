@@ -92,6 +92,16 @@ struct osd_handle {
   bool have_schedule = false, have_weights = false;
   float* w_in_packed = nullptr;      // input_proj.weight zero-padded to [H0][roundup(D,32)] for the LDS-DMA kernel
   int w_in_ld = 0;
+  // D % 4 != 0 (e.g. the reference's real dims 62 + 5054 + 26 = 5142): the reverse chain keeps its state in an internal buffer
+  // whose rows are padded to Dp = roundup(D, 4) floats, so that every operand is 16-byte aligned and the LDS-DMA / FAST tile code
+  // and the chain kernel apply; the pad columns carry finite values that only ever meet zero weights
+  int Dp = 0;
+  bool splitk_suspended = false;     // a chain-kernel fallback re-run in progress: no split-K (bit-identical to the chain kernel)
+  int input_splitk = 0;              // osd_set_option("input_splitk"): 0 off (default: a row's result does not depend on how rows are chunked / sharded),
+                                     // -1 auto (chunks with < 128 input_proj tiles), n = slices
+  float* w_out_packed = nullptr;     // [Dp][H_last]: output_proj.weight + zero rows for the pad columns (allocated iff D % 4)
+  float* b_out_packed = nullptr;     // [Dp]
+  float* chain_xpad = nullptr; int64_t chain_xpad_floats = 0;     // padded chain state of the chain kernel [n][Dp]
   float *d_sqrt_ac = nullptr, *d_sqrt_1m = nullptr, *d_coef = nullptr, *d_time_emb = nullptr, *d_temb = nullptr;
   int64_t chunk_rows = 65536;
   int n_streams = 2;

@@ -16,6 +16,7 @@ hipError_t launch_wgrad_splitk(hipStream_t s, const GemmArgs& g, float* slabs, i
 
 // k_fused.hip ----------------------------------------------------------------------
 hipError_t launch_input(hipStream_t s, const GemmArgs& g, const EpiInput::Args& a, bool a_zero_padded);
+hipError_t launch_input_splitk(hipStream_t s, const GemmArgs& g, const EpiInput::Args& a, float* slabs, int slices);
 hipError_t launch_posterior(hipStream_t s, const GemmArgs& g, const EpiPosterior::Args& a);
 hipError_t launch_mse(hipStream_t s, const GemmArgs& g, const EpiMse::Args& a);
 

@@ -237,8 +237,13 @@ class BiologyAwareDiffusionModel(nn.Module):
         self.chain_stagger: Optional[int] = None
         self.chain_spin_budget: Optional[int] = None      # ticks (100 MHz) a dependency wait inside the chain kernel may take
         self.chain_wall_budget_ms: Optional[int] = None   # host-side budget of a chain (0 / None: 10 x the estimate + 2 s)
+        # per-layer engine, input_proj split-K over workgroups (small-batch latency path): None / 0 off -- a row's result is then
+        # independent of chunking and sharding, bit for bit --, -1 auto (chunks with < 128 input_proj tiles), n = slices.
+        # SyntheticPatientGenerator switches None to auto: its per-scenario batches are the reference's default workload
+        self.input_splitk: Optional[int] = None
         self.last_sampler: Optional[str] = None           # engine the most recent sample() ran on
         self.train_streams: Optional[int] = None      # 1 = whole backward on one stream, 2 (library default) = weight gradients on a side stream
+        self.persistent_bwd: Optional[int] = None     # 1 = dgrad chain + weight gradients as one persistent launch (csrc/bwd_persist.h; library default 0)
         # optional constraint losses (set_constraints); None = the reference's eps-MSE only
         self._constraints = None
         self._constraints_version = 0
@@ -330,6 +335,8 @@ class BiologyAwareDiffusionModel(nn.Module):
             L.check(L.lib().osd_set_option(eng.handle, b"n_streams", int(self.sample_streams)))
         if self.train_streams:
             L.check(L.lib().osd_set_option(eng.handle, b"train_streams", int(self.train_streams)))
+        if self.persistent_bwd is not None:
+            L.check(L.lib().osd_set_option(eng.handle, b"persistent_bwd", int(self.persistent_bwd)))
         try:
             mode = {"auto": 0, "chain": 1, "graph": 2, "layers": 2}[self.sampler]
         except KeyError:
@@ -337,7 +344,7 @@ class BiologyAwareDiffusionModel(nn.Module):
         L.check(L.lib().osd_set_option(eng.handle, b"sampler", mode))
         for name, val in (("chain_grid", self.chain_grid), ("chain_steps_per_launch", self.chain_steps_per_launch),
                           ("chain_stagger", self.chain_stagger), ("chain_spin_budget", self.chain_spin_budget),
-                          ("chain_wall_budget_ms", self.chain_wall_budget_ms)):
+                          ("chain_wall_budget_ms", self.chain_wall_budget_ms), ("input_splitk", self.input_splitk)):
             if val is not None:
                 L.check(L.lib().osd_set_option(eng.handle, name.encode(), int(val)))
         return eng

@@ -24,6 +24,11 @@ class SyntheticPatientGenerator:
     def __init__(self, model, config: dict, device: str = "cuda"):
         self.model = model.to(device)
         self.model.eval()
+        # the reference generates 1000 patients per scenario by default (config.yaml:119): small batches, where input_proj's long
+        # K loop over few output tiles is the step's longest launch -- let the per-layer engine split it over workgroups unless
+        # the caller chose (model.input_splitk = 0 keeps results bit-independent of the batch split)
+        if getattr(self.model, "input_splitk", 0) is None:
+            self.model.input_splitk = -1
         self.config = config
         self.device = device
         self.mutation_dim = model.mutation_dim

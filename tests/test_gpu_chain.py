@@ -20,6 +20,10 @@ def _model(T, hidden=FULL_H, seed=0, **dims):
     d = dict(FULL)
     d.update(dims)
     m = BiologyAwareDiffusionModel(config=config(hidden, T=T), **d).cuda().eval()
+    # bit equality between the two engines is a statement about the single-pass input_proj (the library default); the small-batch
+    # split-K path of the per-layer engine (SyntheticPatientGenerator's default) is another fp32 summation order, covered by
+    # test_input_splitk_small_batches below
+    m.input_splitk = 0
     gen = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():                  # non-trivial GroupNorm affine
         for k, p in m.named_parameters():
@@ -214,3 +218,30 @@ def test_chain_timeout_without_sync_is_reported_by_the_next_call():
     ref, _ = _run(m, cond, n, "graph", seed=3)
     got, _ = _run(m, cond, n, "chain", seed=3)
     assert torch.equal(got, ref)
+
+
+def test_input_splitk_small_batches():
+    """The small-batch latency path of the per-layer engine (the reference's default generation workload: 1000 patients per
+    scenario, config.yaml:119): input_proj's K range cut into slices over workgroups + a reduce/epilogue kernel.  Auto mode
+    engages below 128 output tiles; against the single-pass kernels the chain agrees to the chain tolerance (summation order),
+    against the oracle likewise; graph replay and eager launches stay bit-identical to each other."""
+    T, n = 10, 1000
+    m = _model(T, seed=12)
+    gen = torch.Generator().manual_seed(2)
+    cond = torch.randn(n, 3, generator=gen)
+    x_T = torch.randn(n, 2000, generator=gen)
+    zs = torch.randn(T - 1, n, 2000, generator=gen)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items() if k.startswith(("condition_embed", "unet"))}
+    ref = O.sample(sd, O.schedule_buffers("cosine", T), cond, x_T, lambda t: zs[T - 1 - t], 3, 128)
+    kw = dict(x_T=x_T.cuda(), noise=zs.cuda())
+    single, _ = _run(m, cond.cuda(), n, "graph", **kw)              # input_splitk = 0 (from _model)
+    outs = {}
+    for mode in (-1, 4, 16):
+        m.input_splitk = mode
+        outs[mode], _ = _run(m, cond.cuda(), n, "graph", **kw)
+        assert_close(outs[mode], ref, 5e-5, atol=1e-5, what=f"split-K {mode} vs oracle")
+        assert_close(outs[mode], single, 2e-5, atol=1e-6, what=f"split-K {mode} vs single pass")
+    assert not torch.equal(outs[4], single)                          # it really is another summation order
+    m.use_graph = False
+    eager, _ = _run(m, cond.cuda(), n, "graph", **kw)
+    assert torch.equal(eager, outs[16])

@@ -242,6 +242,63 @@ def test_odd_shapes_vs_oracle(dims, hidden, cond_dim):
         assert_close(p.grad.cpu(), ref_grads[k], 5e-5, atol=1e-8, what=f"grad {k}")
 
 
+@pytest.mark.parametrize("dims,hidden,n", [
+    ((62, 5054, 26), [256, 512, 256], 300),     # the reference's real TARGET-OS dims (config.yaml / QUICKSTART.md:202): D = 5142 = 4 * 1285 + 2
+    ((5, 30, 2), [256, 256], 129),              # D = 37 (one partial quad), one full row tile + 1 row
+])
+def test_unaligned_feature_dim_runs_on_the_padded_state(dims, hidden, n):
+    """D % 4 != 0 with device-generated draws: both engines keep the chain state in an internal buffer whose rows are padded to
+    a multiple of 4 floats (pad columns meet zero weights in input_proj and get eps = 0 from a packed output_proj), so the
+    LDS-DMA / FAST tile code and the persistent chain kernel apply instead of the guarded scalar-load kernels.  Checked (i)
+    against the oracle fed with the device's own Philox draws (osd_op_randn returns exactly what the kernels draw), chain
+    tolerance 5e-5 * max|ref|, mask bit-equal away from the threshold; (ii) chain kernel vs per-layer kernels bit for bit.
+    Reference: models/diffusion.py:427-449, utils/generate.py:135."""
+    import ctypes as C
+    from osteosarcoma_diffusionmodel_amd import _lib as L
+    T, cond_dim = 10, 3
+    D = sum(dims)
+    assert D % 4 != 0
+    conf = config(hidden, T=T)
+    shapes = O.param_shapes(*dims, cond_dim, hidden, 128)
+    sd = O.init_state_dict(shapes, seed=33)
+    m = BiologyAwareDiffusionModel(*dims, cond_dim, conf)
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda().eval()
+    m.input_splitk = 0                          # engines are compared bit for bit below: single-pass input_proj (see test_gpu_chain.py)
+    gen = torch.Generator().manual_seed(6)
+    cond = torch.randn(n, cond_dim, generator=gen)
+    seed, off = (7 << 34) + 99, 11
+    eng = m._engine()
+
+    def draws(step):
+        a = torch.empty(n, D, device="cuda")
+        L.check(L.lib().osd_op_randn(eng.handle, L.ptr(a), n, D, seed, off, step, 0))
+        return a.cpu()
+
+    x_T = draws(T)
+    zs = {t: draws(t) for t in range(1, T)}
+    bufs = O.schedule_buffers("cosine", T)
+    ref = O.sample(sd, bufs, cond, x_T, lambda t: zs[t], len(hidden), 128)
+    m.sampler = "graph"
+    out, mask = m.sample(cond.cuda(), n, seed=seed, row_offset=off, return_mutation_mask=True)
+    assert m.last_sampler == "graph"
+    assert_close(out.cpu(), ref, CHAIN_RTOL, atol=1e-6, what=f"padded-state chain D={D}")
+    md = dims[0]
+    refm = (ref[:, :md] > 0.5).float()
+    near = (ref[:, :md] - 0.5).abs() <= CHAIN_RTOL * ref.abs().max() + 1e-6
+    assert ((mask.cpu() != refm) & ~near).sum().item() == 0
+    assert torch.equal(mask, (out[:, :md] > 0.5).float())
+    # eager launches (no hipGraph) and the persistent chain kernel: same bits
+    m.use_graph = False
+    out_e = m.sample(cond.cuda(), n, seed=seed, row_offset=off)
+    assert torch.equal(out_e, out)
+    m.sampler, m.chain_grid = "chain", 2
+    out_c, mask_c = m.sample(cond.cuda(), n, seed=seed, row_offset=off, return_mutation_mask=True)
+    assert m.last_sampler == "chain"
+    assert torch.equal(out_c, out), f"max|d| = {(out_c - out).abs().max().item():.3e}"
+    assert torch.equal(mask_c, mask)
+
+
 def test_c_abi_error_codes():
     """The C ABI reports misuse through return codes + osd_last_error (never aborts): call order, bad
     arguments, unsupported architectures."""
