@@ -269,6 +269,31 @@ def train_leg(dev, dist, world, rank, steps, backend):
     if world > 1:
         exposed = sum(a.elapsed_time(b) for a, b in ev) / steps
     per_step = dt / steps
+    # the same steps through Trainer.train_epoch over loaders shaped like prepare_data's (utils/train.py:413-437: random_split,
+    # shuffle, drop_last, batch 4096): device-resident epoch path vs the reference's per-batch host hand-over
+    epoch = None
+    if world == 1:
+        from osteosarcoma_diffusionmodel_amd.train import OsteosarcomaDataset
+        ds = object.__new__(OsteosarcomaDataset)
+        ds.data, ds.conditions, ds.survival_days = data.cpu(), cond.cpu(), surv.cpu()
+        tr_ds, va_ds = torch.utils.data.random_split(ds, [rows - 8192, 8192], generator=torch.Generator().manual_seed(42))
+        epoch = {}
+        for resident in (True, False):
+            tr.train_loader = torch.utils.data.DataLoader(tr_ds, batch_size=B, shuffle=True, num_workers=0, drop_last=True)
+            tr.val_loader = torch.utils.data.DataLoader(va_ds, batch_size=B, shuffle=False, num_workers=0)
+            tr.resident = None if resident else False
+            n_ep = 4 if resident else 1
+            tr.train_epoch()                                   # upload / warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_ep):
+                tr.train_epoch()
+            torch.cuda.synchronize()
+            e_dt = (time.perf_counter() - t0) / n_ep
+            n_b = len(tr.train_loader)
+            epoch["resident" if resident else "dataloader"] = {"samples_per_s": round(n_b * B / e_dt, 1), "ms_per_step": round(1e3 * e_dt / n_b, 4),
+                                                               "steps_per_epoch": n_b}
+        epoch["resident_vs_train_step"] = round(epoch["resident"]["samples_per_s"] / (B / per_step), 3)
     tf = TRAIN_FLOP_PER_SAMPLE * B * world / per_step / 1e12
     return {"config": ("DDP diffusion training, %d x MI355X, global batch %d" % (world, B * world)) if world > 1 else
                       "diffusion training, D=2000, T=1000, batch 4096, 1 x MI355X",
@@ -277,6 +302,7 @@ def train_leg(dev, dist, world, rank, steps, backend):
             "frac_of_fp32_mfma_peak": round(tf / world / FP32_MFMA_PEAK_TFLOPS, 4),
             "exposed_comm_ms_per_step": round(exposed, 4), "grad_message_bytes": int(tr.flat.grad.numel()) * 4,
             "comm": None if world == 1 else f"{tr.comm_kind} ({backend})", "final_loss": round(float(loss.item()), 5),
+            "epoch_samples_per_s": None if epoch is None else epoch["resident"]["samples_per_s"], "train_epoch": epoch,
             "includes": "mixup + q_sample + forward + backward + bucketed all-reduce + clip_grad_norm_ + AdamW, dropout 0.2 (Philox)"}
 
 

@@ -158,6 +158,16 @@ int osd_sample_chain(osd_handle *h, const float *cond, int64_t n, const float *x
  * OSD_EHIP from a synchronous call means the kernel did not even react to the abort flag (device hung). */
 int osd_sample_engine(osd_handle *h, int64_t n, int flags);
 
+/* Device-resident epoch path (utils/train.py:204-250 hands every batch over from host memory; here the dataset of
+ * OsteosarcomaDataset (utils/train.py:22-82) stays in HBM).  The NEXT osd_train_loss_fwd_bwd on this handle takes its n rows
+ * from the dataset instead of its x0 / cond arguments (pass NULL there):
+ *   row i  = lam * data[idx_a[i]] + (1 - lam) * data[idx_b[i]]      MixupAugmentation, utils/train.py:117-119, the two
+ *            products rounded separately as torch evaluates them; conditions likewise
+ *   idx_b NULL: no mixup;  idx_a NULL: rows 0 .. n-1.  idx_a / idx_b: dev int64[n].  One-shot: consumed by that call.
+ * Gather, mixup, the draw of t and q_sample run as ONE pass over the batch (SURVEY a5 + a11). */
+int osd_train_batch_source(osd_handle *h, const float *data, int64_t ld_data, const float *cond, int64_t ld_cond,
+                           const int64_t *idx_a, const int64_t *idx_b, double lam);
+
 /* Training forward+backward (models/diffusion.py:344-380 + loss.backward(),
  * utils/train.py:236-239): loss (dev float[1]) and gradients of all parameters.
  *   t_index   dev int32[n] or NULL -> Philox randint

@@ -10,3 +10,29 @@ from .generate import SyntheticPatientGenerator, generate_patients, load_trained
 
 __all__ = ["BiologyAwareDiffusionModel", "BiologyAwareDiffusion", "SyntheticPatientGenerator",
            "generate_patients", "load_trained_model"]
+
+
+def _respect_cpu_quota():
+    """PyTorch sizes its intra-op thread pool by the CPUs it can see (256 on an MI355X host) even when the container's cgroup
+    grants far fewer (cpu.max: 16 cores per GPU on the boxes this was measured on).  One small CPU tensor op per epoch -- an
+    index gather of 57 000 rows -- then wakes the whole OpenMP team, the idle workers spin at the region's barrier, the CFS quota
+    of the 100 ms period is gone, and EVERY thread of the process, HIP's runtime threads included, is frozen until the next
+    period: 60-90 ms GPU stalls on a 100 ms grid (tools/throttle_check.sh: nr_throttled 2 -> 20 during 170 training steps;
+    none with a capped pool, and the epoch loop went from 2.0 to 1.03 ms/step).  Cap the pool at the quota once, at import;
+    OSD_KEEP_TORCH_THREADS=1 leaves torch's setting alone."""
+    import os
+    if os.environ.get("OSD_KEEP_TORCH_THREADS") == "1":
+        return
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota == "max":
+            return
+        cores = max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        return
+    import torch
+    if torch.get_num_threads() > cores:
+        torch.set_num_threads(cores)
+
+
+_respect_cpu_quota()

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "osd_sample_engine": (C.c_int, [_P, C.c_int64, C.c_int]),
     "osd_train_loss_fwd_bwd": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, C.POINTER(_P), C.c_uint64, C.c_int64, C.c_int,
                                          _P, C.POINTER(_P), C.c_double, C.POINTER(_P), C.c_int]),
+    "osd_train_batch_source": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_double]),
     "osd_denoiser_forward_train": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.POINTER(_P), C.c_uint64, C.c_int64, C.c_int, _P]),
     "osd_denoiser_backward": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.POINTER(_P), C.c_uint64, C.c_int64, C.c_int, C.POINTER(_P), _P,
                                         C.POINTER(_P), C.c_int]),

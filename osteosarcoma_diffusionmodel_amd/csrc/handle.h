@@ -6,6 +6,7 @@
 #include <vector>
 #include "../../include/osdiff.h"
 #include "constraints.h"
+#include "batch_src.h"
 
 namespace osd {
 
@@ -119,6 +120,7 @@ struct osd_handle {
   hipStream_t wgrad_stream = nullptr;
   std::vector<hipEvent_t> ev_pool;
   int two_stream_bwd = 1;            // osd_set_option("train_streams", 1|2)
+  osd::BatchSrc batch_src{}; bool have_batch_src = false;      // osd_train_batch_source: one-shot source of the next training call's rows
   int64_t saved_rows = -1;           // rows of the last osd_denoiser_forward_train whose activations are still in the arena
   // constraint losses (osd_set_constraints); parts_dev = (mse, L_pc, L_me) of the last training call
   osd::ConsPlan cons;

@@ -89,6 +89,68 @@ hipError_t launch_q_sample(hipStream_t s, const float* x0, const int* t, const f
   return hipGetLastError();
 }
 
+// The training step's prologue in one pass (SURVEY a5 + a11): batch row r is taken from a device-resident dataset -- row idx_a[r],
+// mixed with row idx_b[r] as MixupAugmentation does (utils/train.py:117-119: lam * v + (1 - lam) * v[perm], products rounded
+// separately, so the result has the bits of the reference's two-step evaluation) -- and goes straight through q_sample; the mixed
+// row itself is only written when somebody needs it (x0_out: the constraint losses).  The row's first thread also mixes the
+// condition row into cond_out.  Replaces gather + k_mixup3 + k_q_sample (three passes over the batch) by one.
+__global__ void k_q_sample_src(BatchSrc b, const int* t, const float* sqrt_ac, const float* sqrt_1m, const float* noise_in, int64_t rows, int cols,
+                               int cd, uint64_t seed, uint32_t row_offset, float* x_t, float* noise_out, int* t_out, int T, float* cond_out,
+                               float* x0_out) {
+  const int c4n = (cols + 3) >> 2;
+  const int64_t total = rows * c4n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4n;
+    const int c = 4 * (int)(i - r * c4n);
+    int tt;
+    if (t) tt = t[r];
+    else {
+      const uint4 rr = philox_at(seed, row_offset + (uint32_t)r, 0u, 0u, TAG_TSTEP);
+      tt = (int)(((uint64_t)rr.x * (uint64_t)T) >> 32);
+      if (c == 0) t_out[r] = tt;
+    }
+    const float a = sqrt_ac[tt], bb = sqrt_1m[tt];
+    const int64_t ia = b.idx_a ? b.idx_a[r] : r;
+    float4 x = ld4g(b.data + ia * b.ldd, c, cols);
+    int64_t ib = 0;
+    if (b.idx_b) {
+      ib = b.idx_b[r];
+      const float4 y = ld4g(b.data + ib * b.ldd, c, cols);
+      x.x = __fadd_rn(__fmul_rn(b.lam, x.x), __fmul_rn(b.oml, y.x));
+      x.y = __fadd_rn(__fmul_rn(b.lam, x.y), __fmul_rn(b.oml, y.y));
+      x.z = __fadd_rn(__fmul_rn(b.lam, x.z), __fmul_rn(b.oml, y.z));
+      x.w = __fadd_rn(__fmul_rn(b.lam, x.w), __fmul_rn(b.oml, y.w));
+    }
+    if (c == 0 && cond_out) {
+      for (int k = 0; k < cd; ++k) {
+        float v = b.cond[ia * b.ldc + k];
+        if (b.idx_b) v = __fadd_rn(__fmul_rn(b.lam, v), __fmul_rn(b.oml, b.cond[ib * b.ldc + k]));
+        cond_out[r * cd + k] = v;
+      }
+    }
+    float4 n;
+    if (noise_in) n = ld4g(noise_in + r * cols, c, cols);
+    else n = randn4(seed, row_offset + (uint32_t)r, (uint32_t)(c >> 2), 0u, TAG_QNOISE);
+    float4 o;
+    o.x = __fadd_rn(__fmul_rn(a, x.x), __fmul_rn(bb, n.x));
+    o.y = __fadd_rn(__fmul_rn(a, x.y), __fmul_rn(bb, n.y));
+    o.z = __fadd_rn(__fmul_rn(a, x.z), __fmul_rn(bb, n.z));
+    o.w = __fadd_rn(__fmul_rn(a, x.w), __fmul_rn(bb, n.w));
+    st4g(x_t + r * cols, c, cols, o);
+    if (noise_out && noise_out != noise_in) st4g(noise_out + r * cols, c, cols, n);
+    if (x0_out) st4g(x0_out + r * cols, c, cols, x);
+  }
+}
+hipError_t launch_q_sample_src(hipStream_t s, const BatchSrc& b, const int* t, const float* sqrt_ac, const float* sqrt_1m, const float* noise_in,
+                               int64_t rows, int cols, int cd, uint64_t seed, uint32_t row_offset, float* x_t, float* noise_out, int* t_out, int T,
+                               float* cond_out, float* x0_out) {
+  if (rows <= 0) return hipSuccess;
+  if (!t && (!t_out || T < 1)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_q_sample_src, ew_grid(rows * ((cols + 3) / 4)), 256, 0, s, b, t, sqrt_ac, sqrt_1m, noise_in, rows, cols, cd, seed,
+                     row_offset, x_t, noise_out, t_out, T, cond_out, x0_out);
+  return hipGetLastError();
+}
+
 // caller-supplied timestep indices clamped into [lo, hi]: an index outside [0, T) is a caller error (the Python
 // shim raises IndexError as the reference's buffer gather would); the clamp only keeps the table gathers in bounds
 __global__ void k_clamp_int(const int* in, int64_t n, int lo, int hi, int* out) {

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include "gemm.h"
 #include "epilogues.h"
+#include "batch_src.h"
 
 namespace osd {
 
@@ -42,6 +43,9 @@ hipError_t launch_copy2d(hipStream_t s, const float* src, int lds, float* dst, i
 hipError_t launch_q_sample(hipStream_t s, const float* x0, const int* t, const float* sqrt_ac, const float* sqrt_1m,
                            const float* noise_in, int64_t rows, int cols, uint64_t seed, uint32_t row_offset,
                            float* x_t, float* noise_out, int* t_out = nullptr, int T = 0);
+hipError_t launch_q_sample_src(hipStream_t s, const BatchSrc& b, const int* t, const float* sqrt_ac, const float* sqrt_1m, const float* noise_in,
+                               int64_t rows, int cols, int cd, uint64_t seed, uint32_t row_offset, float* x_t, float* noise_out, int* t_out, int T,
+                               float* cond_out, float* x0_out);
 hipError_t launch_clamp_int(hipStream_t s, const int* in, int64_t n, int lo, int hi, int* out);
 hipError_t launch_randint(hipStream_t s, int* out, int64_t n, int hi, uint64_t seed, uint32_t row_offset);
 hipError_t launch_mixup(hipStream_t s, const float* v, const int64_t* perm, double lam, int64_t rows, int cols, float* out);

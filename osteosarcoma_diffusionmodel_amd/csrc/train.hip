@@ -19,6 +19,8 @@ constexpr int WG_ROWS_ALIGN = 32;                          // the grouped weight
 struct TrainWs {
   FwdWs f;
   float *x_t, *noise, *d_out, *u0;
+  float* cond_mix;   // [n][cond_dim]: the batch's condition rows when they come from a resident dataset (osd_train_batch_source)
+  float* x0_mix;     // [n][D]: the batch's data rows, only carved when the constraint losses read them
   int* t_idx;
   float *g_h0, *g_ce2, *g_ce1, *g_u, *g_temb;
   std::vector<float*> g_out, g_z2, g_mid, g_z1;
@@ -39,6 +41,7 @@ static int64_t carve_train(const Arch& a, float* base, int64_t n, const ConsPlan
   off = align_up64(fwd);
   w->x_t = take(n * a.D); w->noise = take(n * a.D); w->d_out = take(n * a.D);
   w->u0 = take(n * 64);
+  w->cond_mix = take(n * (int64_t)a.cond_dim);
   w->t_idx = (int*)take(n);
   w->g_h0 = take(n * a.H0); w->g_ce2 = take(n * 64); w->g_ce1 = take(n * 64); w->g_u = take(n * 64);
   w->g_temb = take((int64_t)t_pad(a.T) * a.H0);
@@ -53,9 +56,9 @@ static int64_t carve_train(const Arch& a, float* base, int64_t n, const ConsPlan
   w->partials = take((int64_t)GN_BWD_MAX_BLOCKS * 3 * cmax);
   w->slab_floats = 16 * 1024 * 1024;      // 64 MB of split-K slabs
   w->slabs = take(w->slab_floats);
-  w->pred = w->g_x0 = nullptr;
+  w->pred = w->g_x0 = w->x0_mix = nullptr;
   if (cp) {
-    w->pred = take(n * a.D); w->g_x0 = take(n * a.D);
+    w->pred = take(n * a.D); w->g_x0 = take(n * a.D); w->x0_mix = take(n * a.D);
     const int64_t bytes = cons_carve(*cp, n, a.D, nullptr, &w->cw);
     char* cbase = (char*)take((bytes + 3) / 4);
     cons_carve(*cp, n, a.D, cbase, &w->cw);
@@ -461,7 +464,9 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
                            float* const* grads, double loss_scale, void* const* events, int n_events) {
   OSD_TRY(check_ready(h));
   OSD_TRY(check_rows(n));
-  if (!x0 || !cond || !loss_out) { set_error("null tensor"); return OSD_EINVAL; }
+  const bool from_src = h && h->have_batch_src;          // one-shot: consumed (or dropped) by this call
+  if (h) h->have_batch_src = false;
+  if ((!from_src && (!x0 || !cond)) || !loss_out) { set_error("null tensor"); return OSD_EINVAL; }
   if (n == 0) { set_error("empty batch"); return OSD_EINVAL; }
   OSD_TRY(check_row_offset(row_offset, n));
   const Arch& a = h->arch;
@@ -506,7 +511,15 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   // t ~ randint(0, T) is drawn inside q_sample (one launch less) and kept in w.t_idx for the layers that gather by it
   int* t_draw = nullptr;
   if (!t_idx) { t_draw = w.t_idx; t_idx = w.t_idx; }
-  OSD_HIP(launch_q_sample(s, x0, t_draw ? nullptr : t_idx, h->d_sqrt_ac, h->d_sqrt_1m, noise, n, D, seed, roff, w.x_t, w.noise, t_draw, a.T));
+  if (from_src) {
+    // rows gathered from the resident dataset, mixed up and noised in one pass; conditions land in the workspace
+    OSD_HIP(launch_q_sample_src(s, h->batch_src, t_draw ? nullptr : t_idx, h->d_sqrt_ac, h->d_sqrt_1m, noise, n, D, a.cond_dim, seed, roff, w.x_t,
+                                w.noise, t_draw, a.T, w.cond_mix, cp ? w.x0_mix : nullptr));
+    cond = w.cond_mix;
+    x0 = cp ? w.x0_mix : nullptr;
+  } else {
+    OSD_HIP(launch_q_sample(s, x0, t_draw ? nullptr : t_idx, h->d_sqrt_ac, h->d_sqrt_1m, noise, n, D, seed, roff, w.x_t, w.noise, t_draw, a.T));
+  }
   const float* eps_true = noise ? noise : w.noise;
   OSD_TRY(cond_embed_fwd(h, s, cond, n, w));
   TrainWs& W = w;
@@ -542,6 +555,21 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
 
   OSD_TRY(backward_from(h, s, W, W.x_t, t_idx, cond, n, W.d_out, train, masks, seed, roff, grads, nullptr, events));
   if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
+  return OSD_OK;
+}
+
+int osd_train_batch_source(osd_handle* h, const float* data, int64_t ld_data, const float* cond, int64_t ld_cond, const int64_t* idx_a,
+                           const int64_t* idx_b, double lam) {
+  if (!h) { set_error("null handle"); return OSD_EINVAL; }
+  if (!data || !cond) { set_error("null dataset tensor"); return OSD_EINVAL; }
+  if (ld_data < h->arch.D || ld_cond < h->arch.cond_dim) { set_error("dataset row strides %lld / %lld are smaller than the model's dims", (long long)ld_data, (long long)ld_cond); return OSD_EINVAL; }
+  if (!(lam >= 0.0 && lam <= 1.0)) { set_error("lam must be in [0,1]"); return OSD_EINVAL; }
+  BatchSrc b{};
+  b.data = data; b.ldd = ld_data; b.cond = cond; b.ldc = ld_cond; b.idx_a = idx_a; b.idx_b = idx_b;
+  // python: lam and (1 - lam) are float64 scalars; torch multiplies an fp32 tensor by each as fp32 (launch_mixup)
+  b.lam = (float)lam; b.oml = (float)(1.0 - lam);
+  h->batch_src = b;
+  h->have_batch_src = true;
   return OSD_OK;
 }
 

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import logging
+import time
 from pathlib import Path
 from typing import Dict, List, Optional, Sequence
 
@@ -76,7 +77,7 @@ class FlatParams:
 
 
 def _loss_fwd_bwd(model: BiologyAwareDiffusionModel, x0, cond, grad_ptrs, *, t=None, noise=None, dropout_masks=None,
-                  seed=None, row_offset=0, loss_scale=1.0, events=None, engine=None) -> torch.Tensor:
+                  seed=None, row_offset=0, loss_scale=1.0, events=None, engine=None, source=None) -> torch.Tensor:
     """One call of osd_train_loss_fwd_bwd; returns the 1-element device loss tensor.  ``engine``: the Trainer hands over
     its engine, whose parameter pointers are the flat buffer's views (checked by the Trainer), so the per-call option /
     signature round of ``model._engine()`` is skipped; the call itself re-derives the tables that follow the weights."""
@@ -85,10 +86,20 @@ def _loss_fwd_bwd(model: BiologyAwareDiffusionModel, x0, cond, grad_ptrs, *, t=N
     else:
         eng = engine
         L.check(L.lib().osd_set_stream(eng.handle, C.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)))
-    x0 = model._prep(x0, model.data_dim, "x_0")
-    cond = model._prep(cond, model.condition_dim, "conditions")
-    n = x0.shape[0]
-    t32 = None if t is None else model._t32(t, n, x0.device)
+    if source is not None:
+        # rows of a device-resident dataset (ResidentSplit): gathered, mixed up and noised by the library in one pass
+        data, conds, idx_a, idx_b, lam = source
+        n = idx_a.shape[0]
+        L.check(L.lib().osd_train_batch_source(eng.handle, L.ptr(data), data.stride(0), L.ptr(conds), conds.stride(0), L.ptr(idx_a),
+                                               L.ptr(idx_b), float(lam)))
+        x0 = cond = None
+        dev_ = data.device
+    else:
+        x0 = model._prep(x0, model.data_dim, "x_0")
+        cond = model._prep(cond, model.condition_dim, "conditions")
+        n = x0.shape[0]
+        dev_ = x0.device
+    t32 = None if t is None else model._t32(t, n, dev_)
     nz = None if noise is None else model._prep(noise, model.data_dim, "noise")
     flags = model._flags()
     masks = None
@@ -98,7 +109,7 @@ def _loss_fwd_bwd(model: BiologyAwareDiffusionModel, x0, cond, grad_ptrs, *, t=N
         masks = L.ptr_array(keep)
         flags |= L.OSD_F_TRAIN_MODE
     seed = _draw_seed() if seed is None else seed
-    loss = torch.empty(1, device=x0.device, dtype=torch.float32)
+    loss = torch.empty(1, device=dev_, dtype=torch.float32)
     ev_arr, n_ev = None, 0
     if events is not None:
         ev_arr = (C.c_void_p * len(events))(*[e.cuda_event for e in events])
@@ -281,6 +292,118 @@ class OsteosarcomaDataset(Dataset):
         return {"data": self.data[idx], "conditions": self.conditions[idx], "survival": self.survival_days[idx]}
 
 
+class ResidentSplit:
+    """A DataLoader over (a Subset of) an ``OsteosarcomaDataset`` whose tensors fit in HBM, replayed from the device.
+
+    The reference hands every batch over from host memory (utils/train.py:214-216: per-row ``__getitem__`` dicts, default
+    collate, three pageable host-to-device copies): at the BASELINE shape that is 32 MB per 4096-row batch against a step of
+    one millisecond.  Here ``data`` / ``conditions`` / ``survival_days`` of the dataset are uploaded once and an epoch is the
+    loader's OWN batch order -- its ``batch_sampler`` is iterated, after the one draw ``iter(DataLoader)`` takes from the
+    default generator, so shuffling (per epoch), ``drop_last`` and ``DistributedSampler`` sharding are the loader's, draw for
+    draw -- as an int64 index matrix on the device.  ``build`` returns None when the loader is not of that shape (custom
+    collate, workers, another dataset type, larger than the budget): the Trainer then iterates the DataLoader as before."""
+
+    def __init__(self, loader, base, rows, device):
+        self.loader, self.base, self.rows, self.device = loader, base, rows, device
+
+    @staticmethod
+    def _base_of(ds):
+        idx = None
+        while isinstance(ds, torch.utils.data.Subset):
+            sub = torch.as_tensor(ds.indices, dtype=torch.int64)
+            idx = sub if idx is None else sub[idx]
+            ds = ds.dataset
+        return ds, idx
+
+    @classmethod
+    def build(cls, loader, device, cache: dict, budget_bytes: Optional[int] = None):
+        from torch.utils.data import dataloader as _dl, sampler as _s
+        if not isinstance(loader, DataLoader) or loader.num_workers != 0 or loader.collate_fn is not _dl.default_collate:
+            return None
+        bs = loader.batch_sampler
+        if not isinstance(bs, _s.BatchSampler):
+            return None
+        smp = bs.sampler
+        ok = isinstance(smp, (_s.SequentialSampler, torch.utils.data.distributed.DistributedSampler)) or \
+            (isinstance(smp, _s.RandomSampler) and not smp.replacement)
+        if not ok:
+            return None
+        base, rows = cls._base_of(loader.dataset)
+        if not all(isinstance(getattr(base, k, None), torch.Tensor) for k in ("data", "conditions", "survival_days")):
+            return None
+        if type(base).__getitem__ is not OsteosarcomaDataset.__getitem__:
+            return None                                   # a subclass that transforms rows on access
+        need = 4 * (base.data.numel() + base.conditions.numel() + base.survival_days.numel())
+        if budget_bytes is None:
+            free, _ = torch.cuda.mem_get_info(torch.device(device))
+            budget_bytes = free // 2
+        key = id(base)
+        if key not in cache:
+            if need > budget_bytes:
+                return None
+            dev = torch.device(device)
+            cache[key] = (base.data.to(dev, torch.float32).contiguous(), base.conditions.to(dev, torch.float32).contiguous(),
+                          base.survival_days.to(dev, torch.float32).contiguous())
+        if rows is None:
+            rows = torch.arange(len(base), dtype=torch.int64)
+        return cls(loader, cache[key], rows, device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _upload(self, idx: torch.Tensor) -> torch.Tensor:
+        """Epoch order to the device through one of two pinned staging buffers: a pageable host-to-device copy makes the HIP
+        runtime pin the source on the fly, which was seen to stall later launches for 60-70 ms every few epochs."""
+        dev = torch.device(self.device)
+        if dev.type != "cuda":
+            return idx.to(dev)
+        n = idx.numel()
+        if not hasattr(self, "_stage") or self._stage[0][0].numel() < n:
+            self._stage = [(torch.empty(n, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+            self._stage_i = 0
+        host, ev = self._stage[self._stage_i]
+        self._stage_i ^= 1
+        while not ev.query():
+            time.sleep(20e-6)
+        host[:n].copy_(idx)
+        out = torch.empty(n, dtype=torch.int64, device=dev)
+        out.copy_(host[:n], non_blocking=True)
+        ev.record()
+        return out
+
+    def _sampler_order(self) -> torch.Tensor:
+        """The index sequence ``iter(loader.batch_sampler.sampler)`` yields, as one int64 tensor.  RandomSampler (without
+        replacement, one pass) and SequentialSampler are restated with the sampler's own torch calls -- the same draws from the
+        same generators, without 50 000 Python ints per epoch; anything else is iterated."""
+        from torch.utils.data import sampler as _s
+        smp = self.loader.batch_sampler.sampler
+        n = len(smp.data_source) if hasattr(smp, "data_source") else None
+        if isinstance(smp, _s.SequentialSampler):
+            return torch.arange(n, dtype=torch.int64)
+        if isinstance(smp, _s.RandomSampler) and not smp.replacement and smp.num_samples == n:
+            gen = smp.generator
+            if gen is None:                       # RandomSampler.__iter__: a fresh generator seeded from the default one
+                gen = torch.Generator()
+                gen.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+            return torch.randperm(n, generator=gen)
+        return torch.as_tensor(list(smp), dtype=torch.int64)
+
+    def epoch_indices(self):
+        """[n_batches] list of device int64 tensors: dataset rows of each batch, in the order ``for batch in loader`` visits them."""
+        torch.empty((), dtype=torch.int64).random_(generator=self.loader.generator)     # _BaseDataLoaderIter's base-seed draw
+        order = self._sampler_order()
+        bsz, drop = self.loader.batch_sampler.batch_size, self.loader.batch_sampler.drop_last
+        n_full = order.numel() // bsz
+        keep = n_full * bsz if drop else order.numel()
+        if keep == 0:
+            return []
+        dev = self._upload(self.rows[order[:keep]])
+        out = [dev[i * bsz:(i + 1) * bsz] for i in range(n_full)]
+        if keep > n_full * bsz:
+            out.append(dev[n_full * bsz:])
+        return out
+
+
 class MixupAugmentation:
     """lam ~ Beta(a, a) via numpy, perm via torch.randperm on the host -- the reference's draws
     (utils/train.py:108-115) -- then lam*x + (1-lam)*x[perm] as one HIP gather kernel per tensor."""
@@ -291,22 +414,36 @@ class MixupAugmentation:
         self._ring: list = []          # pinned host buffers for the permutation: an H2D copy from pageable memory would make the
         self._ring_i = 0               # host wait for the whole previous step every iteration
 
-    def __call__(self, batch):
-        data, conditions, survival = batch["data"], batch["conditions"], batch["survival"]
-        n = data.size(0)
+    def draw(self, n: int, device):
+        """The reference's two draws for a batch of n rows (utils/train.py:108-115): lam ~ Beta(alpha, alpha) from numpy's
+        global state, perm = torch.randperm(n) on the host generator; perm is returned on ``device``."""
         lam = np.random.beta(self.alpha, self.alpha) if self.alpha > 0 else 1.0
-        if not data.is_cuda:
-            raise RuntimeError("MixupAugmentation runs on the device: pass ROCm tensors (there is no CPU fallback)")
         if not self._ring or self._ring[0][0].numel() != n:
-            self._ring = [(torch.empty(n, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+            self._ring = [(torch.empty(n, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(16)]
             self._ring_i = 0
         host, ev = self._ring[self._ring_i]
         self._ring_i = (self._ring_i + 1) % len(self._ring)
-        ev.synchronize()               # the copy that last used this buffer (4 steps ago) has finished
+        # the copy that last used this buffer (16 steps ago) must have finished.  Polled: a blocking hipEventSynchronize on an
+        # event that is still pending was seen to return 60-70 ms late every ~25 steps on this stack (tools/epoch_probe.py)
+        while not ev.query():
+            time.sleep(20e-6)
         torch.randperm(n, out=host)    # the reference's draw (utils/train.py:113), on the host generator
-        perm = torch.empty(n, dtype=torch.int64, device=data.device)
+        perm = torch.empty(n, dtype=torch.int64, device=device)
         perm.copy_(host, non_blocking=True)
         ev.record()
+        return lam, perm
+
+    def __call__(self, batch):
+        data, conditions, survival = batch["data"], batch["conditions"], batch["survival"]
+        n = data.size(0)
+        if not data.is_cuda:
+            raise RuntimeError("MixupAugmentation runs on the device: pass ROCm tensors (there is no CPU fallback)")
+        lam, perm = self.draw(n, data.device)
+        return self.mix(batch, lam, perm)
+
+    def mix(self, batch, lam, perm):
+        data, conditions, survival = batch["data"], batch["conditions"], batch["survival"]
+        n = data.size(0)
         d = data.float().contiguous()
         c = conditions.float().contiguous()
         s = survival.float().contiguous()
@@ -407,8 +544,21 @@ class Trainer:
                 self._rccl = RcclGradComm(self.flat.flat.device)
                 self._rccl.set_buckets(self._slices)
             else:
-                self._comm_stream = torch.cuda.Stream()
+                self._comm_stream = torch.cuda.Stream(priority=-1)      # highest: the collective must get in beside the backward pass
         self.global_step = 0
+        # device-resident epoch path (ResidentSplit): None = decide at the first epoch, False = off (the DataLoader is iterated)
+        self.resident = None if tc.get("resident_dataset", True) else False
+        self._resident_cache: dict = {}
+        self._resident_train = self._resident_val = None
+
+    def _resident_splits(self):
+        if self.resident is None:
+            self._resident_train = ResidentSplit.build(self.train_loader, self.device, self._resident_cache)
+            self._resident_val = ResidentSplit.build(self.val_loader, self.device, self._resident_cache)
+            self.resident = self._resident_train is not None
+            if self.resident:
+                logger.info("Dataset is resident in HBM: epochs replay the loader's batch order from device memory")
+        return (self._resident_train, self._resident_val) if self.resident else (None, None)
 
     def _bcast(self, t: torch.Tensor):
         """Broadcast from rank 0 in place (staged through the host when the backend is gloo)."""
@@ -421,7 +571,7 @@ class Trainer:
 
     # one optimisation step on an already device-resident (and mixed) batch
     def train_step(self, data, conditions, survival=None, *, t=None, noise=None, dropout_masks=None, seed=None, comm_events=None,
-                   **vae_kw) -> torch.Tensor:
+                   source=None, **vae_kw) -> torch.Tensor:
         """``comm_events``: an optional pair of timing ``torch.cuda.Event``s recorded on the current stream when its own
         backward has been enqueued and again once it has waited for the gradient exchange -- their distance is the
         exposed (not overlapped) communication time of the step (bench.py)."""
@@ -438,13 +588,15 @@ class Trainer:
             self.optimizer.step()
             self.global_step += 1
             return loss.detach()
+        rows = source[3].shape[0] if source is not None else data.shape[0]
         loss = _loss_fwd_bwd(self.model, data, conditions, self._grad_ptrs, t=t, noise=noise, dropout_masks=dropout_masks, seed=seed,
-                             row_offset=self.rank * data.shape[0], loss_scale=1.0 / self.world, events=self._events, engine=self._engine)
+                             row_offset=self.rank * rows, loss_scale=1.0 / self.world, events=self._events, engine=self._engine,
+                             source=None if source is None else (source[0], source[1], source[3], source[4], source[5]))
         if comm_events is not None:
             comm_events[0].record()
         if self.dist:
             if self._rccl is not None:
-                self._rccl.allreduce(self.model._engine().handle, self.flat.grad, self._events)
+                self._rccl.allreduce(self._engine.handle, self.flat.grad, self._events)      # stream-bound in _loss_fwd_bwd
             else:
                 allreduce_buckets(self.flat.grad, self._slices, self._events, self._comm_stream)
         if comm_events is not None:
@@ -457,6 +609,23 @@ class Trainer:
         """utils/train.py:204-250; the per-step loss stays on the device and is read once per epoch."""
         self.model.train()
         total = torch.zeros(1, device=self.device)
+        res, _ = self._resident_splits()
+        if res is not None:
+            data, cond, surv = res.base
+            for idx in res.epoch_indices():
+                lam, idx_b = 1.0, None
+                if self.mixup is not None:
+                    lam, perm = self.mixup.draw(idx.shape[0], idx.device)
+                    idx_b = idx[perm]
+                if self.is_vae:
+                    d, c, sv = data[idx], cond[idx], surv[idx]
+                    if idx_b is not None:
+                        mixed = self.mixup.mix({"data": d, "conditions": c, "survival": sv}, lam, perm)
+                        d, c, sv = mixed["data"], mixed["conditions"], mixed["survival"]
+                    total += self.train_step(d, c, sv)
+                else:
+                    total += self.train_step(None, None, source=(data, cond, surv, idx, idx_b, lam))
+            return float(total.item()) / max(len(res), 1)
         for batch in self.train_loader:
             data = batch["data"].to(self.device)
             conditions = batch["conditions"].to(self.device)
@@ -472,6 +641,21 @@ class Trainer:
         """utils/train.py:252-273 (eval mode, still random t / noise)."""
         self.model.eval()
         total = torch.zeros(1, device=self.device)
+        _, res = self._resident_splits()
+        if res is not None:
+            data, cond, surv = res.base
+            n_batches = 0
+            for idx in res.epoch_indices():
+                n_batches += 1
+                if self.is_vae:
+                    total += self.model(data[idx], cond[idx], surv[idx])
+                else:
+                    total += _loss_fwd_bwd(self.model, None, None, None, source=(data, cond, idx, None, 1.0))
+            avg = total / max(n_batches, 1)
+            if self.dist:
+                torch.distributed.all_reduce(avg)
+                avg /= self.world
+            return float(avg.item())
         for batch in self.val_loader:
             data = batch["data"].to(self.device)
             conditions = batch["conditions"].to(self.device)

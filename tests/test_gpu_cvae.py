@@ -143,3 +143,56 @@ def test_trainer_runs_cvae_epoch(tmp_path):
     assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "val_loss", "config"}
     assert "vae.encoder.mlp.1.running_mean" in ck["model_state_dict"]
     assert tr.global_step == 10
+
+
+def test_config1_cvae_epoch_at_its_stated_shape(tmp_path):
+    """BASELINE config 1 at the shape SURVEY section 8(d) states: the cVAE (models/cvae.py:222-346) behind the reference's
+    Trainer dispatch (utils/train.py:233-234) on a synthetic "TARGET-OS" cohort generated as QUICKSTART.md:217-241 does but with
+    dims 50 / 1900 / 50 -- mutations randint(0, 2), expression and pathways N(0, 1) (pathways z-scored as prepare_data does),
+    clinical survival_days ~ randint(100, 2000), event_occurred, age_years ~ U(10, 18), metastasis_at_diagnosis, numpy seed 42;
+    the four clinical columns give condition_dim 4 (utils/train.py:395-398); n = 100, val_split 0.2, batch 16 -> 80 training
+    rows, 5 steps per epoch (drop_last).  One epoch must run with a finite loss, a second one must lower it; checkpoint keys
+    as utils/train.py:278-284.  Runs through the OsteosarcomaDataset / DataLoader objects of the pipeline (and hence the
+    device-resident epoch path)."""
+    from osteosarcoma_diffusionmodel_amd.train import OsteosarcomaDataset
+    np.random.seed(42)
+    n = 100
+    ids = [f"TARGET-40-{i:04d}" for i in range(n)]
+    import pandas as pd
+    mut = pd.DataFrame(np.random.randint(0, 2, (n, 50)), index=ids, columns=[f"GENE_{i}" for i in range(50)])
+    expr = pd.DataFrame(np.random.randn(n, 1900), index=ids, columns=[f"EXPR_{i}" for i in range(1900)])
+    path = pd.DataFrame(np.random.randn(n, 50), index=ids, columns=[f"PATHWAY_{i}" for i in range(50)])
+    path = (path - path.mean()) / (path.std() + 1e-8)
+    clinical = pd.DataFrame({"submitter_id": ids, "survival_days": np.random.randint(100, 2000, n), "event_occurred": np.random.randint(0, 2, n),
+                             "age_years": np.random.uniform(10, 18, n), "metastasis_at_diagnosis": np.random.randint(0, 2, n)})
+    clinical["survival_days_norm"] = (clinical["survival_days"] - clinical["survival_days"].mean()) / (clinical["survival_days"].std() + 1e-8)
+    feats = ["survival_days_norm", "event_occurred", "age_years", "metastasis_at_diagnosis"]
+    ds = OsteosarcomaDataset(mut, expr, path, clinical, feats)
+    assert ds.data.shape == (100, 2000) and ds.conditions.shape == (100, 4)
+    tr_ds, va_ds = torch.utils.data.random_split(ds, [80, 20], generator=torch.Generator().manual_seed(42))
+    tl = torch.utils.data.DataLoader(tr_ds, batch_size=16, shuffle=True, num_workers=0, drop_last=True)
+    vl = torch.utils.data.DataLoader(va_ds, batch_size=16, shuffle=False, num_workers=0)
+    # the reference's own model section (config/config.yaml:34-61): latent 128, hidden [256, 512, 256], dropout 0.2
+    conf = {"model": {"latent_dim": 128, "hidden_dims": [256, 512, 256], "gnn": {"dropout": 0.2}, "constraints": CONF["model"]["constraints"]}}
+    conf["training"] = {"learning_rate": 1e-3, "weight_decay": 1e-5, "patience": 100, "min_delta": 1e-4, "augmentation": {"mixup_alpha": 0.2},
+                        "save_dir": str(tmp_path), "num_epochs": 2, "save_frequency": 1, "val_split": 0.2, "random_seed": 42, "batch_size": 16}
+    torch.manual_seed(0)
+    m = BiologyConstrainedVAE(50, 1900, 50, 4, conf)
+    tr = Trainer(m, tl, vl, conf, device="cuda")
+    assert len(tl) == 5
+    hist = tr.train()
+    assert tr.resident is True                                     # the loaders are of prepare_data's shape: replayed from HBM
+    assert tr.global_step == 10
+    assert len(hist["train_loss"]) == 2 and all(np.isfinite(hist["train_loss"])) and all(np.isfinite(hist["val_loss"]))
+    assert hist["train_loss"][1] < hist["train_loss"][0]
+    ck = torch.load(tmp_path / "best_model.pt", map_location="cpu", weights_only=True)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "val_loss", "config"}
+    assert ck["model_state_dict"]["vae.encoder.mlp.0.weight"].shape[1] == 2000 + 4
+    # the same loaders through the reference's per-batch host hand-over: same number of steps, finite
+    conf2 = dict(conf)
+    conf2["training"] = dict(conf["training"], resident_dataset=False, save_dir=str(tmp_path / "b"), num_epochs=1)
+    torch.manual_seed(0)
+    m2 = BiologyConstrainedVAE(50, 1900, 50, 4, conf2)
+    tr2 = Trainer(m2, tl, vl, conf2, device="cuda")
+    h2 = tr2.train()
+    assert tr2.resident is False and tr2.global_step == 5 and np.isfinite(h2["train_loss"][0])

@@ -97,3 +97,92 @@ def test_two_rank_step_equals_single_process(tmp_path, backend, comm):
     # the global loss is the mean of the two shard losses
     for i in range(3):
         assert abs(0.5 * (res[0][1][i] + res[1][1][i]) - ref_losses[i]) < 1e-5 * abs(ref_losses[i])
+
+
+# ---- BASELINE config 4's shape on one device: D = 2000, 4096 rows per rank, dropout on, buckets + events ----------------------
+CFG4_SEED = (5 << 35) + 2024
+FULLD = dict(mutation_dim=50, expression_dim=1900, pathway_dim=50, condition_dim=3)
+
+
+def _conf4(save_dir):
+    return {"model": {"latent_dim": 128, "hidden_dims": [256, 512, 256], "gnn": {"dropout": 0.2},
+                      "diffusion": {"num_steps": 1000, "beta_schedule": "cosine"}, "condition_on": []},
+            "training": {"learning_rate": 1e-4, "weight_decay": 1e-5, "patience": 100, "min_delta": 1e-4,
+                         "augmentation": {"mixup_alpha": 0.0}, "save_dir": save_dir, "num_epochs": 1,
+                         "save_frequency": 10, "val_split": 0.2, "random_seed": 42, "batch_size": 4096}}
+
+
+def _data4(rows):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(rows, 2000, generator=g)
+    x[:, :50] = (x[:, :50] > 0).float()
+    return x, torch.randn(rows, 3, generator=g)
+
+
+def _worker4(rank, world, port, save_dir, q):
+    import torch.distributed as dist
+    from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel
+    from osteosarcoma_diffusionmodel_amd.train import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(10 + rank)       # different initial weights per rank: rank 0's are broadcast
+        m = BiologyAwareDiffusionModel(config=_conf4(save_dir), **FULLD)
+        tr = Trainer(m, [], [], _conf4(save_dir), device="cuda")
+        assert tr.dist and tr._events is not None and len(tr.buckets) == 7
+        m.train()
+        x, c = _data4(4096 * world)
+        sl = slice(rank * 4096, (rank + 1) * 4096)
+        losses = [tr.train_step(x[sl].cuda(), c[sl].cuda(), seed=CFG4_SEED + i).item() for i in range(2)]
+        torch.cuda.synchronize()
+        q.put((rank, losses, float(tr.optimizer.grad_norm.item()), tr.flat.flat.detach().cpu().numpy(), tr.flat.grad.detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_shape_two_ranks_equal_single_process(tmp_path):
+    """BASELINE config 4 on what a 1-GPU box can run: two ranks (gloo, both on cuda:0), D = 2000, 4096 rows per rank, dropout
+    0.2 with the in-kernel Philox masks, t and noise drawn by Philox too -- all addressed by GLOBAL row (row_offset = rank x
+    4096), so the two shards draw exactly what one process draws for its 8192-row batch -- seven gradient buckets with their
+    events, all-reduce of the pre-scaled gradients, fused clip + AdamW.  After two steps both ranks must hold identical
+    parameters, equal to the single process's within the config-2 tolerances (gradient 5e-5 * max|g| per tensor; parameters
+    2e-5 * max|p| plus the gradient tolerance through the first AdamW steps, where the update is lr * sign-like), and the
+    global loss must be the mean of the shard losses (utils/train.py:236-244 under data parallel)."""
+    from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel
+    from osteosarcoma_diffusionmodel_amd.train import Trainer
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    torch.manual_seed(10)                   # rank 0's initial weights
+    m = BiologyAwareDiffusionModel(config=_conf4(str(tmp_path)), **FULLD)
+    tr = Trainer(m, [], [], _conf4(str(tmp_path)), device="cuda")
+    m.train()
+    x, c = _data4(8192)
+    ref_losses = [tr.train_step(x.cuda(), c.cuda(), seed=CFG4_SEED + i).item() for i in range(2)]
+    ref_p, ref_g = tr.flat.flat.detach().cpu().numpy(), tr.flat.grad.detach().cpu().numpy()
+    ref_norm = float(tr.optimizer.grad_norm.item())
+    assert np.array_equal(res[0][3], res[1][3]), "ranks diverged"
+    for i in range(2):
+        assert abs(0.5 * (res[0][1][i] + res[1][1][i]) - ref_losses[i]) < 1e-5 * abs(ref_losses[i])
+    assert abs(res[0][2] - ref_norm) <= 2e-5 * ref_norm
+    lr = 1e-4
+    for (name, p), (o, n) in zip(m.named_parameters(), zip(tr.flat.offsets, [q_.numel() for q_ in tr.flat.params])):
+        g_ref, g_got = ref_g[o:o + n], res[0][4][o:o + n]
+        gmax = np.abs(g_ref).max()
+        assert np.abs(g_got - g_ref).max() <= 5e-5 * gmax + 1e-9, f"clipped gradient {name}"
+        p_ref, p_got = ref_p[o:o + n], res[0][3][o:o + n]
+        # two AdamW steps from zero moments: each moves an element by at most ~lr; where |g| is within the gradient tolerance
+        # of zero the step's sign can flip, so an element may deviate by up to 2 steps x 2 lr there
+        sens = np.where(np.abs(g_ref) <= 20 * 5e-5 * gmax, 4 * lr, 0.05 * lr)
+        assert (np.abs(p_got - p_ref) <= 2e-5 * np.abs(p_ref).max() + sens).all(), f"parameter {name}"

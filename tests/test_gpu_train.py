@@ -322,3 +322,42 @@ def test_wide_condition_grads_vs_oracle(cond_dim, train_streams):
         assert_close(loss.item(), ref_loss, 1e-5, what="loss")
         for k, p in m.named_parameters():
             assert_close(p.grad.cpu(), ref_grads[k], GRAD_RTOL, atol=1e-8, what=f"grad {k} (rep {rep})")
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_train_epoch_paths_give_the_reference_epoch(golden_dir, tmp_path, resident):
+    """Trainer.train_epoch over a DataLoader of fixture g6's 64 rows -- once replayed from HBM (ResidentSplit: rows gathered,
+    mixed up and noised by one kernel, osd_train_batch_source), once iterating the DataLoader as the reference does
+    (utils/train.py:204-250) -- with the reference's recorded lam / perm / t / noise injected: both must land on the
+    reference's post-epoch parameters, and the two paths on each other's."""
+    from osteosarcoma_diffusionmodel_amd.train import OsteosarcomaDataset
+    g = load_golden(golden_dir, "g6_train_epoch")
+    conf = config(SM_H, p=0.0)
+    conf["training"] = {"learning_rate": 1e-4, "weight_decay": 1e-5, "patience": 100, "min_delta": 1e-4,
+                        "augmentation": {"mixup_alpha": 0.2}, "save_dir": str(tmp_path), "num_epochs": 1,
+                        "save_frequency": 10, "val_split": 0.2, "random_seed": 42, "batch_size": 16, "resident_dataset": resident}
+    ds = object.__new__(OsteosarcomaDataset)
+    ds.data, ds.conditions, ds.survival_days = (torch.from_numpy(g[k]).float() for k in ("data", "cond", "surv"))
+    loader = torch.utils.data.DataLoader(ds, batch_size=16, shuffle=False, num_workers=0, drop_last=True)
+    m = BiologyAwareDiffusionModel(config=conf, **SM)
+    m.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd0.")})
+    tr = Trainer(m, loader, loader, conf, device="cuda")
+    step = {"i": 0}
+    tr.mixup.draw = lambda n, device: (float(g["lam"][step["i"]]), dev(g["perm"][step["i"]]))
+    orig = tr.train_step
+
+    def injected(*a, **k):
+        it = step["i"]
+        out = orig(*a, t=dev(g["t"][it]), noise=dev(g["noise"][it]), **k)
+        step["i"] += 1
+        return out
+
+    tr.train_step = injected
+    avg = tr.train_epoch()
+    assert step["i"] == 4 and bool(tr.resident) == resident
+    assert_close(avg, g["avg_loss"], 1e-5, what="epoch loss")
+    sd1 = m.state_dict()
+    for k, _ in m.named_parameters():
+        assert_close(sd1[k].cpu(), g["sd1." + k], 2e-5, atol=1e-8, what=f"param {k}")
+    val = tr.validate()                       # the resident validation pass runs (4 batches of the same rows)
+    assert np.isfinite(val)
