@@ -70,6 +70,9 @@ def parse_args():
     ap.add_argument("--train-only", action="store_true", help="run only the training leg (for rocprofv3 --stats)")
     ap.add_argument("--no-reference-workload", action="store_true", help="skip the reference's default generation workload leg")
     ap.add_argument("--reference-workload-only", action="store_true")
+    ap.add_argument("--no-validate", action="store_true", help="skip the config-5 share leg (3 x 125 000 patients + on-device validation)")
+    ap.add_argument("--validate-only", action="store_true")
+    ap.add_argument("--validate-patients", type=int, default=125_000)
     return ap.parse_args()
 
 
@@ -205,6 +208,91 @@ def reference_workload_leg(dev):
                                 "frac_of_fp32_mfma_peak": round(n * 1000 * flop_row_step / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                                 "vs_quickstart_gpu": round(n / dt / 3.3, 1)})
         del model, gen
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 5, one GPU's share: 3 scenarios x 125 000 patients + on-device validation (utils/validation.py:225-387)
+# ------------------------------------------------------------------------------------------------
+def validate_leg(model, dev, per_scenario=125_000):
+    """Config 5 = 3 clinical scenarios x 1 000 000 patients over 8 GPUs; one GPU's share is 3 x 125 000.  Each scenario is
+    generated (full T = 1000 chain) and validated against a 125 000-row "real" cohort (synthetic: an earlier sample with another
+    seed) -- per metric the device time and the roofline that bounds it, then BiologicalValidator.validate_all through the
+    reference's entry point (DeviceFrame inputs; its Wasserstein-on-PCA part is the reference's own host-side sklearn / scipy
+    code).  MMD: three Gram blocks on fp32 MFMA, 2 D (n^2 + m^2 + n m) FLOP.  KS / pathway coherence / co-occurrence: HBM
+    streams; algorithmic bytes = every element they must read once."""
+    import numpy as np
+    import pandas as pd
+    import torch
+    from osteosarcoma_diffusionmodel_amd.validation import BiologicalValidator, DeviceFrame
+    n, D, md, ed = per_scenario, 2000, 50, 1900
+    mut_cols = [f"GENE_{i}" for i in range(md)]
+    expr_cols = [f"EXPR_{i}" for i in range(ed)]
+    path_cols = [f"PATHWAY_{i}" for i in range(D - md - ed)]
+    rules = [{"mutation": "GENE_0", "pathway": "PATHWAY_0", "direction": "positive"}, {"mutation": "GENE_1", "pathway": "PATHWAY_1", "direction": "negative"}]
+    val = BiologicalValidator({"evaluation": {"driver_genes": mut_cols[:4], "mutually_exclusive_pairs": [[mut_cols[0], mut_cols[1]]],
+                                              "required_correlations": rules}}, device=str(dev))
+    # gene x pathway membership: 10 pathways of 64 expression genes each (pathway coherence uses the first 10 pathways, :144)
+    pgm = pd.DataFrame(0, index=expr_cols, columns=[f"HALLMARK_{i}" for i in range(10)])
+    for i in range(10):
+        pgm.iloc[64 * i:64 * (i + 1), i] = 1
+
+    def sample(seed, cond_row):
+        cond = torch.tensor([cond_row], dtype=torch.float32, device=dev).repeat(n, 1)
+        x, mask = model.sample(cond, n, seed=seed, return_mutation_mask=True)
+        x = torch.nan_to_num(x, nan=0.0, posinf=1e6, neginf=-1e6)      # random-init weights: the un-clamped chain reaches 3e5
+        x[:, :md] = mask
+        return x
+
+    def frames(x):
+        return (DeviceFrame(x[:, :md].contiguous(), mut_cols), DeviceFrame(x[:, md:md + ed].contiguous(), expr_cols),
+                DeviceFrame(x[:, md + ed:].contiguous(), path_cols))
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+
+    rows = [[(s["survival_time"] - 800) / 500, s["event_occurred"], s["metastasis_at_diagnosis"]] for s in SCENARIOS]
+    real = sample(777, rows[2])
+    rm, re_, rp = frames(real)
+    val.compute_mmd(real[:2048], real[:2048])            # warm-up (kernel loading)
+    val.ks_tests(real[:2048], real[:2048])
+    out = {"config": "BASELINE config 5, one GPU's share: 3 scenarios x %d patients, T = 1000, validated against %d real rows" % (n, n),
+           "scenarios": []}
+    for i, row in enumerate(rows):
+        x, t_sample = timed(lambda: sample(2000 + i, row))
+        sm, se, sp = frames(x)
+        # device kernels on their own (no host-side statistics), then the whole of validate_all as the reference runs it
+        mmd, t_mmd = timed(lambda: val.compute_mmd(real, x))
+        _, t_ks = timed(lambda: val.k.ks_extremes(real, x, 100))
+        cols64 = list(range(64))
+        _, t_coh = timed(lambda: (val._mean_offdiag(re_.values, cols64), val._mean_offdiag(se.values, cols64)))
+        _, t_gram = timed(lambda: (val._gram(sm.values, list(range(50))), val._column_sums(sm.values)))
+        allr, t_all = timed(lambda: val.validate_all(rm, re_, rp, sm, se, sp, pathway_gene_matrix=pgm))
+        flop_mmd = 2.0 * D * (n * float(n) * 3)
+        ks_bytes = 100 * 2 * n * 4.0                         # every sample of the 100 tested features once
+        coh_bytes = 2 * 64 * 2 * n * 4.0                     # real + synthetic, 64 genes, moments pass + row pass
+        gram_bytes = 2 * 50 * n * 4.0
+        out["scenarios"].append({
+            "sample_s": round(t_sample, 3), "patients_per_s": round(n / t_sample, 1),
+            "mmd": {"ms": round(1e3 * t_mmd, 2), "value": round(float(mmd), 6), "bound": "mfma", "tflops": round(flop_mmd / t_mmd / 1e12, 2),
+                    "frac": round(flop_mmd / t_mmd / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
+            "ks_extremes_100_features": {"ms": round(1e3 * t_ks, 2), "bound": "hbm", "algorithmic_gbps": round(ks_bytes / t_ks / 1e9, 1),
+                                         "frac": round(ks_bytes / t_ks / 1e9 / HBM_PEAK_GBPS, 4),
+                                         "note": "column gather + 4-pass segmented radix sort + binary-search extremes; p-values are host scalars (scipy kstwo.sf, as ks_2samp)"},
+            "pathway_coherence_64_genes": {"ms": round(1e3 * t_coh, 3), "bound": "hbm", "algorithmic_gbps": round(coh_bytes / t_coh / 1e9, 1),
+                                           "frac": round(coh_bytes / t_coh / 1e9 / HBM_PEAK_GBPS, 4)},
+            "cooccurrence_gram_50_genes": {"ms": round(1e3 * t_gram, 3), "bound": "hbm", "algorithmic_gbps": round(gram_bytes / t_gram / 1e9, 1),
+                                           "frac": round(gram_bytes / t_gram / 1e9 / HBM_PEAK_GBPS, 4)},
+            "validate_all": {"s": round(t_all, 3), "overall_biological_score": round(float(allr.get("overall_biological_score", float("nan"))), 4),
+                             "mmd": round(float(allr["mmd"]), 6), "ks_test_mean_pvalue": round(float(allr["ks_test_mean_pvalue"]), 4),
+                             "keys": len(allr),
+                             "note": "utils/validation.py:300-387 end to end: the device metrics + the reference's own host-side parts (100 scipy kstwo.sf "
+                                     "p-values at N = 62 500, 2 x 1225 chi-square tables, PCA(10) + Wasserstein on 2 x %d x %d values)" % (n, D)}})
+        del x, sm, se, sp
     return out
 
 
@@ -373,6 +461,10 @@ def main():
         if rank == 0:
             print(json.dumps({"reference_workload": reference_workload_leg(dev)}), flush=True)
         return
+    if args.validate_only:
+        if rank == 0:
+            print(json.dumps({"validate": validate_leg(model, dev, args.validate_patients)}), flush=True)
+        return
     if args.train_only:
         tr = train_leg(dev, dist, world, rank, args.train_steps, backend)
         if rank == 0:
@@ -418,6 +510,9 @@ def main():
     refw = None
     if rank == 0 and world == 1 and not args.no_reference_workload and not args.profile_only:
         refw = reference_workload_leg(dev)
+    vleg = None
+    if rank == 0 and world == 1 and not args.no_validate and not args.profile_only:
+        vleg = validate_leg(model, dev, args.validate_patients)
     if rank == 0 and not args.no_cpu_baseline and world == 1 and not args.profile_only:
         cpu = cpu_baseline(model.state_dict(), full_sample=not args.no_cpu_full_sample)   # N = 1 only (one host, one CPU timing)
 
@@ -436,7 +531,7 @@ def main():
             "rccl_ranks": comm_ranks if (world > 1 and backend == "nccl") else None,       # only when the all-reduce really ran over RCCL
             "achieved_tflops_end_to_end": round(value * 1000 * FLOP_PER_PATIENT_STEP / 1e12 / world, 2),
             "frac_of_fp32_mfma_peak_end_to_end": round(value * 1000 * FLOP_PER_PATIENT_STEP / 1e12 / world / FP32_MFMA_PEAK_TFLOPS, 4),
-            "roofline": roof, "train": train, "reference_workload": refw, "cpu_baseline": cpu,
+            "roofline": roof, "train": train, "reference_workload": refw, "validate": vleg, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -38,6 +38,30 @@ def _dev(a, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+class DeviceFrame:
+    """The few DataFrame operations BiologicalValidator touches (``.columns``, ``.values``, column selection, a column's
+    ``.mean()``) over a tensor that already lives on the device: the validator's inputs at BASELINE config 5's size (10^5-10^6
+    generated patients x 2000 features per GPU) never visit the host as a pandas object."""
+
+    def __init__(self, values: torch.Tensor, columns):
+        import pandas as pd
+        self.values = values
+        self.columns = columns if isinstance(columns, pd.Index) else pd.Index(list(columns))
+
+    @property
+    def shape(self):
+        return tuple(self.values.shape)
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return self.values[:, self.columns.get_loc(key)]          # a device vector: .mean() works as on a Series
+        key = list(key)
+        if len(key) == len(self.columns) and all(a == b for a, b in zip(key, self.columns)):
+            return self
+        idx = torch.as_tensor(self.columns.get_indexer(key), device=self.values.device)
+        return DeviceFrame(self.values.index_select(1, idx), key)
+
+
 def _host(a) -> np.ndarray:
     if isinstance(a, torch.Tensor):
         return a.detach().cpu().numpy()
@@ -263,7 +287,7 @@ class BiologicalValidator:
         drivers = [g for g in self.driver_genes if g in real_mutations.columns]
         if drivers:
             sfreq_all = self.comm.sum(self._column_sums(sfull)) / n_synth
-            rd = np.array([float(real_mutations[g].mean()) for g in drivers])
+            rd = np.array([float(real_mutations[g].mean()) for g in drivers])       # Series.mean() or a device vector's
             sd = np.array([sfreq_all[spos[g]] for g in drivers])       # KeyError if a driver gene is missing, as the reference
             results["driver_gene_frequency_diff"] = float(np.abs(rd - sd).mean())
             logger.info(f"Driver gene frequency difference: {results['driver_gene_frequency_diff']:.3f}")
@@ -344,8 +368,13 @@ class BiologicalValidator:
         if pathway_gene_matrix is not None:
             all_results.update(self.validate_pathway_coherence(real_expression, synth_expression, pathway_gene_matrix))
         all_results.update(self.validate_mutation_expression_correlation(synth_mutations, synth_expression, synth_pathways))
-        real_combined = np.concatenate([real_mutations.values, real_expression.values, real_pathways.values], axis=1)
-        synth_combined = np.concatenate([synth_mutations.values, synth_expression.values, synth_pathways.values], axis=1)
+        parts_r = [real_mutations.values, real_expression.values, real_pathways.values]
+        parts_s = [synth_mutations.values, synth_expression.values, synth_pathways.values]
+        if all(isinstance(p, torch.Tensor) for p in parts_r + parts_s):          # DeviceFrame inputs: stay on the device
+            real_combined, synth_combined = torch.cat(parts_r, dim=1), torch.cat(parts_s, dim=1)
+        else:
+            real_combined = np.concatenate([_host(p) for p in parts_r], axis=1)
+            synth_combined = np.concatenate([_host(p) for p in parts_s], axis=1)
         all_results.update(self.statistical_tests(real_combined, synth_combined))
         logger.info("=" * 50)
         logger.info("VALIDATION SUMMARY")
