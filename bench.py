@@ -324,13 +324,17 @@ def train_leg(dev, dist, world, rank, steps, backend):
     surv = torch.rand(rows, device=dev, generator=g)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
+    order = torch.arange(rows, device=dev, dtype=torch.int64)
+
     def one(i, timed):
+        # a batch of the device-resident dataset (Trainer's epoch path, ResidentSplit): the mixup draws are the reference's
+        # (np.random.beta, torch.randperm on the host), the rows are gathered, mixed and noised by one kernel
         o = (i * B) % (rows - B)
-        sl = slice(o, o + B)
-        mixed = tr.mixup({"data": data[sl], "conditions": cond[sl], "survival": surv[sl]})
+        idx = order[o:o + B]
+        lam, perm = tr.mixup.draw(B, idx.device)
         # the exposed-communication event pair only exists under data parallel: two timing events cost the single-GPU step
         # two barrier packets (~10 us) for a number that is zero by construction
-        return tr.train_step(mixed["data"], mixed["conditions"], comm_events=ev[i] if (timed and world > 1) else None)
+        return tr.train_step(None, None, source=(data, cond, surv, idx, idx[perm], lam), comm_events=ev[i] if (timed and world > 1) else None)
 
     # 20 untimed steps: the first few pay one-off costs (kernel loading, work-list uploads, allocator growth), and on every box
     # one more host-side stall of ~4 ms shows up between steps 10 and 15 (tools/probes/train_steps.py); from step 15 on the

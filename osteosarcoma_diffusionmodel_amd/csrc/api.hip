@@ -166,6 +166,7 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
     const int kx = in.kx > 0 ? in.kx : a.D;
     g.A = h->w_in_packed; g.lda = h->w_in_ld; g.B0 = in.x; g.ldb0 = in.ldx; g.K0 = kx;
     g.F = a.H0; g.P = n; g.K = kx;
+    if (in.a_unpacked) { g.A = h->params[pm.in_w]; g.lda = a.D; g.a_kmax = a.D; }
     EpiInput::Args ea{h->params[pm.in_b], h->d_temb, a.H0, in.t_index, in.t_dev, in.t_imm, ws.cproj, a.H0, ws.h0, a.H0};
     bool done = false;
     if (in.in_slices > 1 && in.in_slabs) {
@@ -224,12 +225,13 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
 // Derived copies that follow the current parameters: the t_emb table time_proj(TimeEmbedding(t/T))
 // (models/diffusion.py:222-223; all rows of a sampling step share t and training rows gather their
 // t, so the Linear runs T times, not B) and the zero-padded input_proj.weight.
-int refresh_derived(osd_handle* h, hipStream_t s) {
+int refresh_derived(osd_handle* h, hipStream_t s, bool pack_in_w) {
   const Arch& a = h->arch;
   GemmArgs g{};
   g.A = h->params[a.pm.tp_w]; g.lda = a.time_dim; g.B0 = h->d_time_emb; g.ldb0 = a.time_dim; g.K0 = a.time_dim;
   g.F = a.H0; g.P = a.T; g.K = a.time_dim;
   OSD_HIP(launch_linear(s, g, true, true, h->params[a.pm.tp_b], h->d_temb, a.H0, false, false));
+  if (!pack_in_w) return OSD_OK;        // a training step that reads input_proj.weight directly (the next osd_load_weights packs it)
   OSD_HIP(launch_copy2d(s, h->params[a.pm.in_w], a.D, h->w_in_packed, h->w_in_ld, a.H0, a.D));   // pad columns stay zero
   if (h->w_out_packed) {                       // D % 4 != 0: rows [D, Dp) stay zero
     const size_t hl = (size_t)a.block_out[a.n_blocks - 1];
@@ -355,6 +357,8 @@ int osd_create(const osd_config* cfg, osd_handle** out) {
   if (const char* e = getenv("OSD_WGRAD_MID_FLUSH")) h->wgrad_mid_flush = atoi(e) != 0;
   if (const char* e = getenv("OSD_FUSED_GN_BWD")) h->fused_gn_bwd = atoi(e) != 0;
   if (const char* e = getenv("OSD_PERSISTENT_BWD")) h->persistent_bwd = atoi(e) != 0;
+  if (const char* e = getenv("OSD_TRAIN_INPUT_SPLITK")) h->train_input_splitk = atoi(e);
+  if (const char* e = getenv("OSD_DUAL_DGRAD")) h->dual_dgrad = atoi(e) != 0;
   const int rc = create_device_state(h);
   if (rc != OSD_OK) {                 // nothing of a half-built handle survives (osd_destroy frees what was allocated)
     osd_destroy(h);
@@ -431,6 +435,16 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "input_splitk")) {            // per-layer sampling engine: 0 off (default), -1 auto (batches with < 128 input_proj tiles), n slices
     if (value < -1 || value > 64) { set_error("input_splitk must be in [-1,64]"); return OSD_EINVAL; }
     h->input_splitk = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "dual_dgrad")) {
+    if (value < 0 || value > 1) { set_error("dual_dgrad must be 0 or 1"); return OSD_EINVAL; }
+    h->dual_dgrad = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "train_input_splitk")) {
+    if (value < 0 || value > 16) { set_error("train_input_splitk must be in [0,16]"); return OSD_EINVAL; }
+    h->train_input_splitk = (int)value;
     return OSD_OK;
   }
   if (!strcmp(name, "chain_spin_budget")) {       // s_memrealtime ticks (100 MHz) a dependency wait inside the chain kernel may take

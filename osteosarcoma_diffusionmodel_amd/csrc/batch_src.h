@@ -13,4 +13,7 @@ struct BatchSrc {
   float lam, oml;                      // lam and (1 - lam), each rounded to fp32 as torch does with python scalars
 };
 
+// buffers a training call zeroes before anything accumulates into them (atomically summed gradients, the loss word)
+struct ZeroList { float* ptr[128]; int64_t count[128]; int n; };
+
 }  // namespace osd

@@ -9,6 +9,8 @@ namespace osd {
 struct TrunkIn {
   const float* x; int ldx; int64_t n;
   float* in_slabs; int in_slices; // > 1: input_proj split-K over that many slices (k_fused.hip), slabs = in_slices x n x H0 floats
+  bool a_unpacked;               // input_proj reads input_proj.weight itself (clamped at D, GemmArgs::a_kmax) instead of the packed copy;
+                                 // x must then be zero in the columns [D, kx) (training: the library's own x_t buffer)
   int kx;                        // K extent of input_proj: 0 = D; Dp when x is the padded chain state (handle.h)
   const int* t_index;            // per-row t (training) or null
   const int* t_dev; int t_imm;   // shared t: device counter (sampling chain) or immediate
@@ -22,7 +24,7 @@ int ensure_arena(Slot* s, int64_t floats);
 int64_t carve_fwd(const Arch& a, float* base, int64_t n, bool train, FwdWs* ws);
 int run_cond(osd_handle* h, hipStream_t s, const float* cond, int64_t n, const FwdWs& ws);
 int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in);
-int refresh_derived(osd_handle* h, hipStream_t s);
+int refresh_derived(osd_handle* h, hipStream_t s, bool pack_in_w = true);
 GemmArgs output_proj_args(osd_handle* h, const FwdWs& ws, int64_t n, bool padded = false);
 int check_ready(osd_handle* h);
 int check_rows(int64_t n);

@@ -10,8 +10,8 @@
 //
 // Preconditions (checked by the host, glds_ok()): 16-byte aligned operands, lda/ldb % 4 == 0,
 // the A operand (weights) readable and ZERO for k in [K, roundup(K,32)) -- true when
-// K % 32 == 0 or when the caller hands a zero-padded packed copy -- and K0 % 32 == 0 for a
-// two-panel B.  B's K tail is clamped to valid addresses (finite data times zero weights).
+// K % 32 == 0 or when the caller hands a zero-padded packed copy; or (GemmArgs::a_kmax) A clamped
+// at its true extent and the B operand zero beyond it -- and K0 % 32 == 0 for a two-panel B.  B's K tail is clamped to valid addresses (finite data times zero weights).
 // Rows beyond F / P re-read the last valid row: they only feed accumulators never stored.
 #pragma once
 #include "gemm.h"
@@ -124,14 +124,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
   const auto pre = Epi::template prefetch<T::NFB, true>(ea, f0 + wf, lane, g.F);
 
   // ---- staging addresses: wave-instruction (j*4 + wave) moves rows 8*(j*4+wave) .. +7 ----
-  int a_off[G::NA];
+  int a_off[G::NA], a_k4[G::NA];
   int b_k4[G::NB], b_lrow[G::NB];
 #pragma unroll
   for (int j = 0; j < G::NA; ++j) {
     const int row = (j * 4 + wave) * 8 + (lane >> 3);
     int rg = f0 + row;
     rg = rg < g.F ? rg : g.F - 1;
-    a_off[j] = rg * g.lda + 4 * ((lane & 7) ^ ((row >> 1) & 7));
+    a_k4[j] = 4 * ((lane & 7) ^ ((row >> 1) & 7));
+    a_off[j] = rg * g.lda + a_k4[j];
   }
 #pragma unroll
   for (int j = 0; j < G::NB; ++j) {
@@ -158,7 +159,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
   // piece j in [0, NA + NB): A pieces first
   auto stage_piece = [&](const StageCtx& c, int j) {
     if (j < G::NA) {
-      glds16(g.A + (size_t)(a_off[j] + c.ak), __builtin_amdgcn_readfirstlane(c.la + (unsigned)j * 4096u));
+      int adj = 0;
+      if (g.a_kmax > 0) {                        // uniform: clamp the 16-byte chunk into [0, a_kmax) (finite duplicates x B's zeros)
+        const int k = c.ak + a_k4[j];
+        adj = k < g.a_kmax - 4 ? 0 : g.a_kmax - 4 - k;
+      }
+      glds16(g.A + (size_t)(a_off[j] + c.ak + adj), __builtin_amdgcn_readfirstlane(c.la + (unsigned)j * 4096u));
     } else {
       const int jb = j - G::NA;
       int k = c.bk + b_k4[jb];

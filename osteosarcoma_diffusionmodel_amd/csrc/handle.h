@@ -97,6 +97,8 @@ struct osd_handle {
   // whose rows are padded to Dp = roundup(D, 4) floats, so that every operand is 16-byte aligned and the LDS-DMA / FAST tile code
   // and the chain kernel apply; the pad columns carry finite values that only ever meet zero weights
   int Dp = 0;
+  int dual_dgrad = 1;                // osd_set_option("dual_dgrad", 0|1): a decoder block's two input dgrads in one launch (k_gnbwd.hip)
+  int train_input_splitk = 0;        // osd_set_option("train_input_splitk"): K slices of input_proj in the training forward (0 / 1 = single pass)
   bool splitk_suspended = false;     // a chain-kernel fallback re-run in progress: no split-K (bit-identical to the chain kernel)
   int input_splitk = 0;              // osd_set_option("input_splitk"): 0 off (default: a row's result does not depend on how rows are chunked / sharded),
                                      // -1 auto (chunks with < 128 input_proj tiles), n = slices

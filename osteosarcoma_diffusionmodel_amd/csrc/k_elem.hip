@@ -51,8 +51,25 @@ hipError_t launch_copy2d(hipStream_t s, const float* src, int lds, float* dst, i
 // products then one add, as torch evaluates it.
 // t == null: the row's timestep is drawn here -- torch.randint(0, T, (B,)) stand-in of models/diffusion.py:361, the same Philox
 // word k_randint uses -- and written to t_out by the row's first thread.
+// x_t rows have a stride of ldxt >= cols floats; the pad columns [cols, ldxt) are written as zeros (the training forward's
+// input_proj reads them against clamped weights, gemm.h: a_kmax).  zl: buffers of the training call that must be zero before
+// anything accumulates into them -- zeroed here, by the same grid, instead of by a launch of their own.
+__device__ __forceinline__ void zero_list(const ZeroList& zl) {
+  for (int e = 0; e < zl.n; ++e) {
+    float* p = zl.ptr[e];
+    const int64_t n = zl.count[e];
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) p[j] = 0.f;
+  }
+}
+__device__ __forceinline__ void zero_pad(float* row, int cols, int ldxt, int c) {
+  if (c + 4 >= cols)
+    for (int k = cols; k < ldxt; ++k) row[k] = 0.f;
+}
+
 __global__ void k_q_sample(const float* x0, const int* t, const float* sqrt_ac, const float* sqrt_1m, const float* noise_in,
-                           int64_t rows, int cols, uint64_t seed, uint32_t row_offset, float* x_t, float* noise_out, int* t_out, int T) {
+                           int64_t rows, int cols, uint64_t seed, uint32_t row_offset, float* x_t, int ldxt, float* noise_out, int* t_out, int T,
+                           ZeroList zl) {
+  zero_list(zl);
   const int c4n = (cols + 3) >> 2;
   const int64_t total = rows * c4n;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -75,17 +92,20 @@ __global__ void k_q_sample(const float* x0, const int* t, const float* sqrt_ac, 
     o.y = __fadd_rn(__fmul_rn(a, x.y), __fmul_rn(b, n.y));
     o.z = __fadd_rn(__fmul_rn(a, x.z), __fmul_rn(b, n.z));
     o.w = __fadd_rn(__fmul_rn(a, x.w), __fmul_rn(b, n.w));
-    st4g(x_t + r * cols, c, cols, o);
+    st4g(x_t + r * ldxt, c, cols, o);
+    zero_pad(x_t + r * ldxt, cols, ldxt, c);
     if (noise_out && noise_out != noise_in) st4g(noise_out + r * cols, c, cols, n);
   }
 }
 hipError_t launch_q_sample(hipStream_t s, const float* x0, const int* t, const float* sqrt_ac, const float* sqrt_1m,
                            const float* noise_in, int64_t rows, int cols, uint64_t seed, uint32_t row_offset,
-                           float* x_t, float* noise_out, int* t_out, int T) {
+                           float* x_t, float* noise_out, int* t_out, int T, int ldxt, const ZeroList* zl) {
   if (rows <= 0) return hipSuccess;
   if (!t && (!t_out || T < 1)) return hipErrorInvalidValue;
+  ZeroList z{};
+  if (zl) z = *zl;
   hipLaunchKernelGGL(k_q_sample, ew_grid(rows * ((cols + 3) / 4)), 256, 0, s, x0, t, sqrt_ac, sqrt_1m, noise_in, rows, cols, seed,
-                     row_offset, x_t, noise_out, t_out, T);
+                     row_offset, x_t, ldxt > 0 ? ldxt : cols, noise_out, t_out, T, z);
   return hipGetLastError();
 }
 
@@ -95,8 +115,9 @@ hipError_t launch_q_sample(hipStream_t s, const float* x0, const int* t, const f
 // row itself is only written when somebody needs it (x0_out: the constraint losses).  The row's first thread also mixes the
 // condition row into cond_out.  Replaces gather + k_mixup3 + k_q_sample (three passes over the batch) by one.
 __global__ void k_q_sample_src(BatchSrc b, const int* t, const float* sqrt_ac, const float* sqrt_1m, const float* noise_in, int64_t rows, int cols,
-                               int cd, uint64_t seed, uint32_t row_offset, float* x_t, float* noise_out, int* t_out, int T, float* cond_out,
-                               float* x0_out) {
+                               int cd, uint64_t seed, uint32_t row_offset, float* x_t, int ldxt, float* noise_out, int* t_out, int T, float* cond_out,
+                               float* x0_out, ZeroList zl) {
+  zero_list(zl);
   const int c4n = (cols + 3) >> 2;
   const int64_t total = rows * c4n;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -136,18 +157,21 @@ __global__ void k_q_sample_src(BatchSrc b, const int* t, const float* sqrt_ac, c
     o.y = __fadd_rn(__fmul_rn(a, x.y), __fmul_rn(bb, n.y));
     o.z = __fadd_rn(__fmul_rn(a, x.z), __fmul_rn(bb, n.z));
     o.w = __fadd_rn(__fmul_rn(a, x.w), __fmul_rn(bb, n.w));
-    st4g(x_t + r * cols, c, cols, o);
+    st4g(x_t + r * ldxt, c, cols, o);
+    zero_pad(x_t + r * ldxt, cols, ldxt, c);
     if (noise_out && noise_out != noise_in) st4g(noise_out + r * cols, c, cols, n);
     if (x0_out) st4g(x0_out + r * cols, c, cols, x);
   }
 }
 hipError_t launch_q_sample_src(hipStream_t s, const BatchSrc& b, const int* t, const float* sqrt_ac, const float* sqrt_1m, const float* noise_in,
                                int64_t rows, int cols, int cd, uint64_t seed, uint32_t row_offset, float* x_t, float* noise_out, int* t_out, int T,
-                               float* cond_out, float* x0_out) {
+                               float* cond_out, float* x0_out, int ldxt, const ZeroList* zl) {
   if (rows <= 0) return hipSuccess;
   if (!t && (!t_out || T < 1)) return hipErrorInvalidValue;
+  ZeroList z{};
+  if (zl) z = *zl;
   hipLaunchKernelGGL(k_q_sample_src, ew_grid(rows * ((cols + 3) / 4)), 256, 0, s, b, t, sqrt_ac, sqrt_1m, noise_in, rows, cols, cd, seed,
-                     row_offset, x_t, noise_out, t_out, T, cond_out, x0_out);
+                     row_offset, x_t, ldxt > 0 ? ldxt : cols, noise_out, t_out, T, cond_out, x0_out, z);
   return hipGetLastError();
 }
 

@@ -42,10 +42,10 @@ hipError_t launch_fill_randn(hipStream_t s, float* out, int ld, int64_t rows, in
 hipError_t launch_copy2d(hipStream_t s, const float* src, int lds, float* dst, int ldd, int64_t rows, int cols);
 hipError_t launch_q_sample(hipStream_t s, const float* x0, const int* t, const float* sqrt_ac, const float* sqrt_1m,
                            const float* noise_in, int64_t rows, int cols, uint64_t seed, uint32_t row_offset,
-                           float* x_t, float* noise_out, int* t_out = nullptr, int T = 0);
+                           float* x_t, float* noise_out, int* t_out = nullptr, int T = 0, int ldxt = 0, const ZeroList* zl = nullptr);
 hipError_t launch_q_sample_src(hipStream_t s, const BatchSrc& b, const int* t, const float* sqrt_ac, const float* sqrt_1m, const float* noise_in,
                                int64_t rows, int cols, int cd, uint64_t seed, uint32_t row_offset, float* x_t, float* noise_out, int* t_out, int T,
-                               float* cond_out, float* x0_out);
+                               float* cond_out, float* x0_out, int ldxt = 0, const ZeroList* zl = nullptr);
 hipError_t launch_clamp_int(hipStream_t s, const int* in, int64_t n, int lo, int hi, int* out);
 hipError_t launch_randint(hipStream_t s, int* out, int64_t n, int hi, uint64_t seed, uint32_t row_offset);
 hipError_t launch_mixup(hipStream_t s, const float* v, const int64_t* perm, double lam, int64_t rows, int cols, float* out);

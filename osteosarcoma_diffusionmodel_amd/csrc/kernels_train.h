@@ -2,10 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "batch_src.h"
 
 namespace osd {
 
-struct ZeroList { float* ptr[128]; int64_t count[128]; int n; };
 hipError_t launch_zero_many(hipStream_t s, const ZeroList& zl);
 
 hipError_t launch_silu_fwd(hipStream_t s, const float* u, float* y, int64_t total);
@@ -49,6 +49,7 @@ struct GnBwdEpi {
 struct GemmArgs;
 bool dgrad_gnbwd_supported(int gw);
 hipError_t launch_dgrad_gnbwd(hipStream_t s, const GemmArgs& g, int gw, const GnBwdEpi& a);
+hipError_t launch_dgrad_gnbwd_dual(hipStream_t s, const GemmArgs& g1, int gw, const GnBwdEpi& a, const GemmArgs& g2, float* out2, int ldo2);
 struct GnColItem { const float* gy; int ldy; const float* z; int ldz; const float* stats; int C, gw; int64_t rows; float* dgamma; float* dbeta; };
 hipError_t launch_gn_colsums(hipStream_t s, const GnColItem* d_items, int n_items, int64_t max_rows);
 

@@ -72,7 +72,8 @@ hipError_t launch_gemm_v(hipStream_t s, const GemmArgs& g, const typename Epi::A
 // guarantees A is readable and zero for k in [K, roundup(K, BK)).
 inline bool glds_ok(const GemmArgs& g, bool a_zero_padded) {
   if (!ptr_al16(g.A) || !ptr_al16(g.B0) || g.lda % 4 || g.ldb0 % 4 || g.K < 4 || g.K % 4) return false;
-  if (g.K % BK && !a_zero_padded) return false;
+  if (g.K % BK && !a_zero_padded && g.a_kmax <= 0) return false;
+  if (g.a_kmax > 0 && (g.a_kmax % 4 || g.a_kmax < 4 || g.a_kmax > g.K || g.K % BK)) return false;
   if (g.K0 < g.K && (g.K0 % BK || (g.K - g.K0) % 4 || g.K - g.K0 < 4 || !ptr_al16(g.B1) || g.ldb1 % 4)) return false;
   return true;
 }
@@ -112,6 +113,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, const typename Epi::Arg
       return launch_gemm_glds<T, Epi>(s, g, ea);
     }
   }
+  if (g.a_kmax > 0) return hipErrorInvalidValue;     // a clamped A operand exists in the LDS-DMA kernel only: the caller must not get here
   if (gemm_fast_ok(g, AKC, BKC) && Epi::fast_ok(ea, g.F)) return launch_gemm_v<T, AKC, BKC, Epi, true>(s, g, ea);
   return launch_gemm_v<T, AKC, BKC, Epi, false>(s, g, ea);
 }

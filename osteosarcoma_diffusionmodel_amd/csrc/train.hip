@@ -18,6 +18,7 @@ constexpr int WG_ROWS_ALIGN = 32;                          // the grouped weight
 
 struct TrainWs {
   FwdWs f;
+  int xld;           // row stride of x_t: D, or roundup(D, 32) with zero pad columns (input_proj then reads the unpacked weight)
   float *x_t, *noise, *d_out, *u0;
   float* cond_mix;   // [n][cond_dim]: the batch's condition rows when they come from a resident dataset (osd_train_batch_source)
   float* x0_mix;     // [n][D]: the batch's data rows, only carved when the constraint losses read them
@@ -33,13 +34,16 @@ struct TrainWs {
   ConsWs cw;
 };
 
+static int x_t_stride(const Arch& a, const ConsPlan* cp) { return (cp || a.D % 4) ? a.D : (a.D + 31) / 32 * 32; }
+
 static int64_t carve_train(const Arch& a, float* base, int64_t n, const ConsPlan* cp, TrainWs* w) {
   int64_t off = 0;
   auto take = [&](int64_t floats) { float* p = base ? base + off : nullptr; off += align_up64(floats); return p; };
   float* fbase = base;
   const int64_t fwd = carve_fwd(a, fbase, n, true, &w->f);
   off = align_up64(fwd);
-  w->x_t = take(n * a.D); w->noise = take(n * a.D); w->d_out = take(n * a.D);
+  w->xld = x_t_stride(a, cp);
+  w->x_t = take(n * (int64_t)w->xld); w->noise = take(n * a.D); w->d_out = take(n * a.D);
   w->u0 = take(n * 64);
   w->cond_mix = take(n * (int64_t)a.cond_dim);
   w->t_idx = (int*)take(n);
@@ -142,20 +146,20 @@ static void add_backward_zeros(const Arch& a, const TrainWs& w, float* const* gr
 }
 
 
-// the handle's low-priority side stream (weight-gradient leaves of the backward pass, the conditioning branch of the forward)
+// the handle's side stream (memory-bound leaves of the backward pass: GroupNorm affine gradients, small weight gradients).
+// Default priority: a LOW-priority stream makes the HIP runtime open a low-priority hardware queue, and streams created later
+// in the process -- e.g. the sampling slots of a model built after a training run, the reference's `--steps train generate` --
+// were seen to land on it: their launch-bound hipGraph replays then ran 3.3x slower (bench.py reference_workload: 3700 -> 1130
+// patients/s).  The leaves no longer need the low priority anyway: the grouped weight-gradient launch runs on the main stream.
 static int side_stream(osd_handle* h, hipStream_t* out) {
-  if (!h->wgrad_stream) {
-    int lo = 0, hi = 0;
-    OSD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    OSD_HIP(hipStreamCreateWithPriority(&h->wgrad_stream, hipStreamNonBlocking, lo));
-  }
+  if (!h->wgrad_stream) OSD_HIP(hipStreamCreateWithFlags(&h->wgrad_stream, hipStreamNonBlocking));
   *out = h->wgrad_stream;
   return OSD_OK;
 }
 
 // The backward pass from dL/d eps_hat (d_out [n][D]) to every parameter gradient (and optionally dL/dx_t), over the
 // activations a training-mode forward left in W.
-static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* x_t, const int* t_idx, const float* cond, int64_t n,
+static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* x_t, int x_ld, const int* t_idx, const float* cond, int64_t n,
                          const float* d_out, bool train, const float* const* masks, uint64_t seed, uint32_t roff, float* const* grads,
                          float* dx_t, void* const* events, bool try_persist = true) {
   const Arch& a = h->arch;
@@ -315,7 +319,8 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   // dgrad whose epilogue is the GroupNorm+SiLU(+dropout) backward of `ln` (z / stats of that layer): writes dL/dz and dL/dy
   auto dgrad_fused = [&](const float* w, int ldw, int kin, const float* gz_next, int ldg, int nout, const LayerDesc& ln, const float* z,
                          const float* stats, float* gz_out, float* gy_buf, bool accumulate, bool with_drop, int blk,
-                         int dep0 = -1, int dep1 = -1, int sig = -1) -> int {
+                         int dep0 = -1, int dep1 = -1, int sig = -1, const float* w_skip = nullptr, int kin_skip = 0, float* out_skip = nullptr,
+                         bool* skip_done = nullptr) -> int {
     GemmArgs g{};
     g.A = w; g.lda = ldw; g.B0 = gz_next; g.ldb0 = ldg; g.K0 = nout; g.F = kin; g.P = (int)n; g.K = nout;
     GnBwdEpi e{};
@@ -327,7 +332,17 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     if (pb) {
       if (!pb->add_dgrad({ln.gw, with_drop ? 1 : 0, g, e, dep0, dep1, sig})) pb_failed = true;
     } else {
-      OSD_HIP(launch_dgrad_gnbwd(s, g, ln.gw, e));
+      bool launched = false;
+      if (w_skip && h->dual_dgrad) {
+        // the skip connection's share of the same gz (plain dX = gz W_skip) rides in the same launch
+        GemmArgs g2{};
+        g2.A = w_skip; g2.lda = ldw; g2.B0 = gz_next; g2.ldb0 = ldg; g2.K0 = nout; g2.F = kin_skip; g2.P = (int)n; g2.K = nout;
+        const hipError_t de = launch_dgrad_gnbwd_dual(s, g, ln.gw, e, g2, out_skip, kin_skip);
+        if (de == hipSuccess) { launched = true; if (skip_done) *skip_done = true; }
+        else if (de != hipErrorInvalidValue) OSD_HIP(de);
+        else (void)hipGetLastError();
+      }
+      if (!launched) OSD_HIP(launch_dgrad_gnbwd(s, g, ln.gw, e));
     }
     cols.push_back({gy_buf, kin, z, kin, stats, kin, ln.gw, n, grads[ln.gamma], grads[ln.beta]});
     return OSD_OK;
@@ -366,6 +381,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     if (fuse) {
       // dL/dz of the second half is in g_z2[b] (left by the dgrad above it); bias gradients ride with the weight gradients
       const int tz1 = pb ? t_z1[b] : -2, tz2 = pb ? t_z2[b] : -2;      // -2: not a persistent pass
+      bool skip_done = false;
       OSD_TRY(wg(W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C, grads[l2.b], nullptr, nullptr, tz2));
       OSD_TRY(dgrad_fused(h->params[l2.w], C, C, W.g_z2[b], C, C, l1, W.f.z1[b], W.f.st1[b], W.g_z1[b], W.g_mid[b], false, drop, b, tz2, -1, tz1));
       OSD_TRY(wg(xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt, grads[l1.b], nullptr, nullptr, tz1));
@@ -378,9 +394,10 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
         const LayerDesc& lp = a.layers[2 * (b - 1) + 1];      // the layer that produced this block's main input
         // an encoder output already holds its skip gradient (written by the decoder block that popped it): second dependency
         OSD_TRY(dgrad_fused(h->params[l1.w], Kt, l1.K1, W.g_z1[b], C, C, lp, W.f.z2[b - 1], W.f.st2[b - 1], W.g_z2[b - 1], W.g_out[b - 1], acc,
-                            false, b - 1, tz1, (pb && acc) ? t_skip[b - 1] : -1, pb ? t_z2[b - 1] : -1));
+                            false, b - 1, tz1, (pb && acc) ? t_skip[b - 1] : -1, pb ? t_z2[b - 1] : -1,
+                            l1.K2 > 0 ? h->params[l1.w] + l1.K1 : nullptr, l1.K2, l1.K2 > 0 ? W.g_out[skip_block] : nullptr, &skip_done));
       }
-      if (l1.K2 > 0) OSD_TRY(dgrad_plain(h->params[l1.w] + l1.K1, Kt, l1.K2, W.g_z1[b], C, C, W.g_out[skip_block], l1.K2, tz1, pb ? t_skip[skip_block] : -1));
+      if (l1.K2 > 0 && !skip_done) OSD_TRY(dgrad_plain(h->params[l1.w] + l1.K1, Kt, l1.K2, W.g_z1[b], C, C, W.g_out[skip_block], l1.K2, tz1, pb ? t_skip[skip_block] : -1));
       continue;
     }
     // second half: GroupNorm+SiLU backward, wgrad, dgrad
@@ -411,9 +428,9 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   // input_proj, time_proj, cond_proj, ConditionalEmbedding  (h0 = x W^T + b + t_emb[t] + c_proj)
   // h0 = x W^T + b_in + (t_emb W_t^T + b_t)[t] + (c W_c^T + b_c): the three biases share one gradient, the column sums of g_h0
   if (pb) {
-    OSD_TRY(wg(x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D, grads[pm.in_b], grads[pm.cp_b], grads[pm.tp_b], t_h0));
+    OSD_TRY(wg(x_t, x_ld, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D, grads[pm.in_b], grads[pm.cp_b], grads[pm.tp_b], t_h0));
     OSD_TRY(wg(W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64, nullptr, nullptr, nullptr, t_h0));
-    if (pb_failed) return backward_from(h, s, W, x_t, t_idx, cond, n, d_out, train, masks, seed, roff, grads, dx_t, events, false);
+    if (pb_failed) return backward_from(h, s, W, x_t, x_ld, t_idx, cond, n, d_out, train, masks, seed, roff, grads, dx_t, events, false);
     OSD_TRY(pb->launch(h, s, W.slabs, W.slab_floats, seed, roff));
     pb = nullptr;                       // the rest of the pass (the conditioning branch) runs launch by launch
   }
@@ -422,7 +439,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   if (!builder.empty()) {
     // input_proj / cond_proj weight gradients went with the persistent launch
   } else {
-    OSD_TRY(wg(x_t, D, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D, grads[pm.in_b], grads[pm.cp_b], grads[pm.tp_b]));
+    OSD_TRY(wg(x_t, x_ld, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D, grads[pm.in_b], grads[pm.cp_b], grads[pm.tp_b]));
     OSD_TRY(wg(W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64));
   }
   OSD_HIP(launch_scatter_rows(s, W.g_h0, t_idx, n, a.H0, W.g_temb));
@@ -491,21 +508,24 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   OSD_TRY(ensure_train_ws(h, s, n, cp, &w));
   h->saved_rows = -1;                    // the workspace no longer matches an osd_denoiser_forward_train call
 
-  // ---- zero everything that is accumulated atomically ----
+  // ---- everything that is accumulated atomically must start at zero: zeroed by the q_sample kernel's own grid ----
+  ZeroList zl{};
   {
-    ZeroList zl{};
     auto add = [&](float* p, int64_t c) { zl.ptr[zl.n] = p; zl.count[zl.n] = c; ++zl.n; };
     add(loss_out, 1);
     if (cp) add(h->parts_dev, 3);
     if (cp && grads) add(w.g_x0, n * (int64_t)D);
     if (grads) add_backward_zeros(a, w, grads, &zl);
     if (zl.n > 128) { set_error("too many parameter tensors"); return OSD_EUNSUPPORTED; }
-    OSD_HIP(launch_zero_many(s, zl));
   }
 
   // ---- forward (models/diffusion.py:361-377) ----
-  // the t_emb table and the padded input_proj.weight follow the current parameters
-  OSD_TRY(refresh_derived(h, s));
+  // x_t rows are padded to whole K steps with zeros when nothing else reads them with the dense stride: input_proj then takes
+  // input_proj.weight as it is (clamped at D) and the per-step packed copy of that weight is not made
+  const bool split_in = h->train_input_splitk > 1 && (int64_t)h->train_input_splitk * n * a.H0 <= w.slab_floats;
+  const bool unpacked = w.xld > D && !split_in;
+  // the t_emb table (and, unless input_proj reads the weight itself, its padded copy) follow the current parameters
+  OSD_TRY(refresh_derived(h, s, !unpacked));
   const int* t_idx = nullptr;
   OSD_TRY(sanitize_t(h, s, t_index, n, &t_idx));
   // t ~ randint(0, T) is drawn inside q_sample (one launch less) and kept in w.t_idx for the layers that gather by it
@@ -514,18 +534,22 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   if (from_src) {
     // rows gathered from the resident dataset, mixed up and noised in one pass; conditions land in the workspace
     OSD_HIP(launch_q_sample_src(s, h->batch_src, t_draw ? nullptr : t_idx, h->d_sqrt_ac, h->d_sqrt_1m, noise, n, D, a.cond_dim, seed, roff, w.x_t,
-                                w.noise, t_draw, a.T, w.cond_mix, cp ? w.x0_mix : nullptr));
+                                w.noise, t_draw, a.T, w.cond_mix, cp ? w.x0_mix : nullptr, w.xld, &zl));
     cond = w.cond_mix;
     x0 = cp ? w.x0_mix : nullptr;
   } else {
-    OSD_HIP(launch_q_sample(s, x0, t_draw ? nullptr : t_idx, h->d_sqrt_ac, h->d_sqrt_1m, noise, n, D, seed, roff, w.x_t, w.noise, t_draw, a.T));
+    OSD_HIP(launch_q_sample(s, x0, t_draw ? nullptr : t_idx, h->d_sqrt_ac, h->d_sqrt_1m, noise, n, D, seed, roff, w.x_t, w.noise, t_draw, a.T, w.xld, &zl));
   }
   const float* eps_true = noise ? noise : w.noise;
   OSD_TRY(cond_embed_fwd(h, s, cond, n, w));
   TrainWs& W = w;
   TrunkIn in{};
-  in.x = W.x_t; in.ldx = D; in.n = n; in.t_index = t_idx; in.train = train; in.save = grads != nullptr;
+  in.x = W.x_t; in.ldx = W.xld; in.kx = unpacked ? W.xld : D; in.a_unpacked = unpacked;
+  in.n = n; in.t_index = t_idx; in.train = train; in.save = grads != nullptr;
   in.masks = masks; in.seed = seed; in.row_offset = roff; in.drop_step = 0;
+  // input_proj at the training batch: 256 output tiles of 63 sequential K steps, one workgroup per CU -- optionally K in slices
+  // over more workgroups (k_fused.hip: partial tiles to slabs, then sum + epilogue); the slab workspace is idle during forward
+  if (split_in) { in.in_slabs = W.slabs; in.in_slices = h->train_input_splitk; }
   OSD_TRY(run_trunk(h, s, W.f, in));
   {
     GemmArgs g = output_proj_args(h, W.f, n);
@@ -553,7 +577,7 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   }
   if (!grads) return OSD_OK;
 
-  OSD_TRY(backward_from(h, s, W, W.x_t, t_idx, cond, n, W.d_out, train, masks, seed, roff, grads, nullptr, events));
+  OSD_TRY(backward_from(h, s, W, W.x_t, W.xld, t_idx, cond, n, W.d_out, train, masks, seed, roff, grads, nullptr, events));
   if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
   return OSD_OK;
 }
@@ -622,7 +646,7 @@ int osd_denoiser_backward(osd_handle* h, const float* x_t, const int32_t* t_inde
   ZeroList zl{};
   add_backward_zeros(a, W, grads, &zl);
   OSD_HIP(launch_zero_many(s, zl));
-  OSD_TRY(backward_from(h, s, W, x_t, t_idx, cond, n, dout, (flags & OSD_F_TRAIN_MODE) != 0, masks, seed, (uint32_t)row_offset, grads, dx_t, events));
+  OSD_TRY(backward_from(h, s, W, x_t, a.D, t_idx, cond, n, dout, (flags & OSD_F_TRAIN_MODE) != 0, masks, seed, (uint32_t)row_offset, grads, dx_t, events));
   if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
   return OSD_OK;
 }
