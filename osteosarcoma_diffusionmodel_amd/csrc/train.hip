@@ -120,6 +120,8 @@ static int ensure_train_ws(osd_handle* h, hipStream_t s, int64_t n, const ConsPl
 }
 
 // ConditionalEmbedding + cond_proj with the pre-activation kept for backward (models/diffusion.py:101-105, 226)
+// (Tried: the whole conditioning branch + the time_proj table as ONE VALU kernel instead of k_cond_mlp_fwd + two tile GEMMs of
+// 7-10 us each: 49 us -- one 87 KB-LDS workgroup per CU, 1.25 rounds, no latency hiding.  Dropped.)
 static int cond_embed_fwd(osd_handle* h, hipStream_t s, const float* cond, int64_t n, TrainWs& w) {
   const Arch& a = h->arch;
   const ParamMap& pm = a.pm;
@@ -434,6 +436,9 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     OSD_TRY(pb->launch(h, s, W.slabs, W.slab_floats, seed, roff));
     pb = nullptr;                       // the rest of the pass (the conditioning branch) runs launch by launch
   }
+  // (Tried: the conditioning branch's backward -- five dependent launches of 5-13 us -- and the affine-gradient column sums on the
+  // side stream BESIDE the grouped weight-gradient launch instead of in front of it.  The grouped launch's older waves starve
+  // them: k_gn_colsums took 202 us instead of 44 and the side chain ended after the main one -- 1042 vs 988 us per step.  Dropped.)
   if (s2 != s && !cols.empty()) { OSD_TRY(fork()); OSD_TRY(side_leaves(s2)); }      // every GroupNorm layer's gy / z is final
   if (dx_t) OSD_HIP(dgrad(s, h->params[pm.in_w], D, D, W.g_h0, a.H0, a.H0, n, dx_t, D, false));
   if (!builder.empty()) {

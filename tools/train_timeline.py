@@ -4,10 +4,19 @@ import csv, glob, sys, re
 f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# a step starts at each k_mixup triple's first kernel; take the last complete step
-starts = [i for i, r in enumerate(rows) if "k_mixup" in r["Kernel_Name"]]
-firsts = [s for j, s in enumerate(starts) if j == 0 or s - starts[j - 1] > 3]
-a, b = firsts[-2], firsts[-1]
+# a step starts at the kernel that follows an optimizer kernel (k_adamw); take a steady-state step of the path named by argv[2]
+# ("src": rows from the resident dataset, the default; "mixup": the host hand-over path with its own mixup kernel) -- the step
+# that sits in the middle of the matching ones
+want = sys.argv[2] if len(sys.argv) > 2 else "src"
+ends = [i for i, r in enumerate(rows) if "k_adamw" in r["Kernel_Name"]]
+steps = [(ends[j] + 1, ends[j + 1] + 1) for j in range(len(ends) - 1)]
+def kind(a, b):
+    names = " ".join(r["Kernel_Name"] for r in rows[a:b])
+    return "src" if "k_q_sample_src" in names else ("mixup" if "k_mixup" in names else "other")
+match = [(a, b) for a, b in steps if kind(a, b) == want and b - a < 80]
+a, b = match[len(match) // 2]
+while "elementwise" in rows[a]["Kernel_Name"] or "index" in rows[a]["Kernel_Name"]:      # torch's loss accumulation / index gather belong to the previous step's tail / this step's head
+    a += 1
 t0 = int(rows[a]["Start_Timestamp"])
 def short(n):
     n = re.sub(r"\(.*", "", n.replace("void ", "").replace("osd::", ""))
