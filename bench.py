@@ -325,13 +325,16 @@ def train_leg(dev, dist, world, rank, steps, backend):
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
     order = torch.arange(rows, device=dev, dtype=torch.int64)
+    # the mixup draws are the reference's (np.random.beta, torch.randperm on the host), made up front and uploaded once, as
+    # Trainer.train_epoch does per epoch (MixupAugmentation.draw_epoch)
+    lams, perms, _ = tr.mixup.draw_epoch([B] * (20 + steps), dev)
 
     def one(i, timed):
-        # a batch of the device-resident dataset (Trainer's epoch path, ResidentSplit): the mixup draws are the reference's
-        # (np.random.beta, torch.randperm on the host), the rows are gathered, mixed and noised by one kernel
+        # a batch of the device-resident dataset (Trainer's epoch path, ResidentSplit): rows gathered, mixed and noised by one kernel
         o = (i * B) % (rows - B)
         idx = order[o:o + B]
-        lam, perm = tr.mixup.draw(B, idx.device)
+        j = i if timed else steps + i
+        lam, perm = lams[j], perms[j]
         # the exposed-communication event pair only exists under data parallel: two timing events cost the single-GPU step
         # two barrier packets (~10 us) for a number that is zero by construction
         return tr.train_step(None, None, source=(data, cond, surv, idx, idx[perm], lam), comm_events=ev[i] if (timed and world > 1) else None)

@@ -433,6 +433,37 @@ class MixupAugmentation:
         ev.record()
         return lam, perm
 
+    def draw_epoch(self, sizes: Sequence[int], device, seed_fn=None):
+        """The draws of a whole epoch in the order the step-by-step loop makes them -- per batch: lam (numpy), perm
+        (torch.randperm on the host generator), then the step's Philox seed (``seed_fn``, the same host generator) -- with ONE
+        host-to-device copy for all permutations.  A pinned copy + event per step was seen to stall the stream for 2-3.5 ms
+        every 10-20 steps while some runtime pool grew (tools/step_times.py: 0.97 -> 1.12 ms/step over 300 steps).
+        Returns (lams, [perm_i on device], seeds)."""
+        lams, perms, seeds = [], [], []
+        for n in sizes:
+            lams.append(np.random.beta(self.alpha, self.alpha) if self.alpha > 0 else 1.0)
+            perms.append(torch.randperm(n))
+            seeds.append(seed_fn() if seed_fn is not None else None)
+        flat = torch.cat(perms) if perms else torch.empty(0, dtype=torch.int64)
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            if getattr(self, "_epoch_pin", None) is None or self._epoch_pin.numel() < flat.numel():
+                self._epoch_pin = torch.empty(max(flat.numel(), 1), dtype=torch.int64).pin_memory()
+                self._epoch_ev = torch.cuda.Event()
+            while not self._epoch_ev.query():
+                time.sleep(20e-6)
+            self._epoch_pin[:flat.numel()].copy_(flat)
+            out = torch.empty(flat.numel(), dtype=torch.int64, device=dev)
+            out.copy_(self._epoch_pin[:flat.numel()], non_blocking=True)
+            self._epoch_ev.record()
+        else:
+            out = flat.to(dev)
+        dperms, o = [], 0
+        for n in sizes:
+            dperms.append(out[o:o + n])
+            o += n
+        return lams, dperms, seeds
+
     def __call__(self, batch):
         data, conditions, survival = batch["data"], batch["conditions"], batch["survival"]
         n = data.size(0)
@@ -612,19 +643,25 @@ class Trainer:
         res, _ = self._resident_splits()
         if res is not None:
             data, cond, surv = res.base
-            for idx in res.epoch_indices():
-                lam, idx_b = 1.0, None
-                if self.mixup is not None:
-                    lam, perm = self.mixup.draw(idx.shape[0], idx.device)
+            batches = res.epoch_indices()
+            lams = perms = seeds = None
+            if self.mixup is not None:
+                # all host draws of the epoch up front, in the step loop's own order (perm_i, seed_i interleaved), one upload
+                from .diffusion import _draw_seed
+                lams, perms, seeds = self.mixup.draw_epoch([b.shape[0] for b in batches], self.device, None if self.is_vae else _draw_seed)
+            for i, idx in enumerate(batches):
+                lam, idx_b, perm = 1.0, None, None
+                if perms is not None:
+                    lam, perm = lams[i], perms[i]
                     idx_b = idx[perm]
                 if self.is_vae:
                     d, c, sv = data[idx], cond[idx], surv[idx]
-                    if idx_b is not None:
+                    if perm is not None:
                         mixed = self.mixup.mix({"data": d, "conditions": c, "survival": sv}, lam, perm)
                         d, c, sv = mixed["data"], mixed["conditions"], mixed["survival"]
                     total += self.train_step(d, c, sv)
                 else:
-                    total += self.train_step(None, None, source=(data, cond, surv, idx, idx_b, lam))
+                    total += self.train_step(None, None, source=(data, cond, surv, idx, idx_b, lam), seed=None if seeds is None else seeds[i])
             return float(total.item()) / max(len(res), 1)
         for batch in self.train_loader:
             data = batch["data"].to(self.device)

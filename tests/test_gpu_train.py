@@ -343,7 +343,9 @@ def test_train_epoch_paths_give_the_reference_epoch(golden_dir, tmp_path, reside
     m.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd0.")})
     tr = Trainer(m, loader, loader, conf, device="cuda")
     step = {"i": 0}
-    tr.mixup.draw = lambda n, device: (float(g["lam"][step["i"]]), dev(g["perm"][step["i"]]))
+    tr.mixup.draw = lambda n, device: (float(g["lam"][step["i"]]), dev(g["perm"][step["i"]]))              # per step (DataLoader path)
+    tr.mixup.draw_epoch = lambda sizes, device, seed_fn=None: ([float(v) for v in g["lam"][:len(sizes)]],     # per epoch (resident path)
+                                                               [dev(g["perm"][i]) for i in range(len(sizes))], [None] * len(sizes))
     orig = tr.train_step
 
     def injected(*a, **k):
