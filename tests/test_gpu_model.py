@@ -299,6 +299,32 @@ def test_unaligned_feature_dim_runs_on_the_padded_state(dims, hidden, n):
     assert torch.equal(mask_c, mask)
 
 
+def test_generate_scenarios_batches_the_scenarios_into_one_chain():
+    """utils/generate.py:146-175 returns one dict per scenario; here the scenarios share ONE reverse chain (rows k*N .. (k+1)*N-1 =
+    scenario k): the result must equal model.sample on the concatenated condition rows with the same seed, split by scenario,
+    with the mutation mask the threshold of the same rows; ``batched=False`` keeps the reference's loop."""
+    conf = config(SM_H, T=8)
+    m = BiologyAwareDiffusionModel(config=conf, **SM).cuda().eval()
+    gen = SyntheticPatientGenerator(m, conf, device="cuda")
+    scen = [{"name": "a", "conditions": {"survival_time": 2000, "event_occurred": 0, "metastasis_at_diagnosis": 0}},
+            {"name": "b", "conditions": {"survival_time": 300, "event_occurred": 1, "metastasis_at_diagnosis": 1}},
+            {"name": "c", "conditions": {"survival_time": 800, "event_occurred": 0, "metastasis_at_diagnosis": 0}}]
+    n = 37
+    out = gen.generate_scenarios(scen, n, seed=99)
+    assert list(out) == ["a", "b", "c"]
+    cond = torch.cat([gen.create_conditions(n, s["conditions"]) for s in scen])
+    ref = m.sample(cond, 3 * n, seed=99).cpu().numpy()
+    for k, s in enumerate(scen):
+        r = out[s["name"]]
+        rows = slice(k * n, (k + 1) * n)
+        assert r["mutations"].shape == (n, 8) and r["expression"].shape == (n, 24) and r["pathways"].shape == (n, 8)
+        assert np.array_equal(r["expression"], ref[rows, 8:32]) and np.array_equal(r["pathways"], ref[rows, 32:])
+        assert np.array_equal(r["mutations"], (ref[rows, :8] > 0.5).astype(float))
+        assert np.array_equal(r["conditions"], cond[rows].cpu().numpy())
+    loop = gen.generate_scenarios(scen, n, batched=False)
+    assert list(loop) == ["a", "b", "c"] and all(loop[k]["expression"].shape == (n, 24) for k in loop)
+
+
 def test_c_abi_error_codes():
     """The C ABI reports misuse through return codes + osd_last_error (never aborts): call order, bad
     arguments, unsupported architectures."""
