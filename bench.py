@@ -559,7 +559,7 @@ def roofline_leg(model, args, cond, offset, dev, engine_used, sample_ms, step_fn
     from osteosarcoma_diffusionmodel_amd import _lib as L
     eng = model._engine()
     T = CONF["model"]["diffusion"]["num_steps"]
-    traffic_files = [ROOT / "profiles" / n for n in ("r02_traffic.json", "r01_traffic.json")]
+    traffic_files = [ROOT / "profiles" / n for n in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")]
 
     def traffic_for(key, scale_units):
         for tj in traffic_files:

@@ -12,5 +12,5 @@ run lds SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run tcc TCC_HIT_sum TCC_MISS_sum
-python3 tools/pmc_summary.py $out r02 5000000 > $out/summary.md; cat $out/summary.md
+python3 tools/pmc_summary.py $out r03 5000000 > $out/summary.md; cat $out/summary.md
 find $out -type f ! -name "summary.md" ! -name "*.log" -delete
