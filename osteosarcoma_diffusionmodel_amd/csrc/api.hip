@@ -167,6 +167,7 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
     g.A = h->w_in_packed; g.lda = h->w_in_ld; g.B0 = in.x; g.ldb0 = in.ldx; g.K0 = kx;
     g.F = a.H0; g.P = n; g.K = kx;
     if (in.a_unpacked) { g.A = h->params[pm.in_w]; g.lda = a.D; g.a_kmax = a.D; }
+    g.ksplit = in.ksplit ? 1 : 0;
     EpiInput::Args ea{h->params[pm.in_b], h->d_temb, a.H0, in.t_index, in.t_dev, in.t_imm, ws.cproj, a.H0, ws.h0, a.H0};
     bool done = false;
     if (in.in_slices > 1 && in.in_slabs) {
@@ -190,7 +191,7 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
       const int skip_block = a.n_enc - 1 - (b - a.n_enc - 1);   // LIFO: decoder j pops encoder n_enc-1-j
       g.B1 = ws.out[skip_block]; g.ldb1 = a.block_out[skip_block];
     }
-    g.F = l1.N; g.P = n; g.K = l1.K1 + l1.K2;
+    g.F = l1.N; g.P = n; g.K = l1.K1 + l1.K2; g.ksplit = in.ksplit ? 1 : 0;
     GnArgs ga{};
     ga.bias = h->params[l1.b]; ga.gamma = h->params[l1.gamma]; ga.beta = h->params[l1.beta];
     ga.out = ws.mid[b]; ga.ldo = l1.N;
@@ -209,7 +210,7 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
     OSD_TRY(prof_mark(h, s));
     GemmArgs g2{};
     g2.A = h->params[l2.w]; g2.lda = l2.K1; g2.B0 = ws.mid[b]; g2.ldb0 = l1.N; g2.K0 = l2.K1;
-    g2.F = l2.N; g2.P = n; g2.K = l2.K1;
+    g2.F = l2.N; g2.P = n; g2.K = l2.K1; g2.ksplit = in.ksplit ? 1 : 0;
     GnArgs gb{};
     gb.bias = h->params[l2.b]; gb.gamma = h->params[l2.gamma]; gb.beta = h->params[l2.beta];
     gb.out = ws.out[b]; gb.ldo = l2.N;
@@ -359,6 +360,7 @@ int osd_create(const osd_config* cfg, osd_handle** out) {
   if (const char* e = getenv("OSD_PERSISTENT_BWD")) h->persistent_bwd = atoi(e) != 0;
   if (const char* e = getenv("OSD_TRAIN_INPUT_SPLITK")) h->train_input_splitk = atoi(e);
   if (const char* e = getenv("OSD_DUAL_DGRAD")) h->dual_dgrad = atoi(e) != 0;
+  if (const char* e = getenv("OSD_TRAIN_KSPLIT")) h->train_ksplit = atoi(e) != 0;
   const int rc = create_device_state(h);
   if (rc != OSD_OK) {                 // nothing of a half-built handle survives (osd_destroy frees what was allocated)
     osd_destroy(h);
@@ -435,6 +437,11 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "input_splitk")) {            // per-layer sampling engine: 0 off (default), -1 auto (batches with < 128 input_proj tiles), n slices
     if (value < -1 || value > 64) { set_error("input_splitk must be in [-1,64]"); return OSD_EINVAL; }
     h->input_splitk = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "train_ksplit")) {            // 1: the training forward's GEMMs use two wave groups per workgroup (gemm_glds.h, NG = 2)
+    if (value < 0 || value > 1) { set_error("train_ksplit must be 0 or 1"); return OSD_EINVAL; }
+    h->train_ksplit = (int)value;
     return OSD_OK;
   }
   if (!strcmp(name, "dual_dgrad")) {

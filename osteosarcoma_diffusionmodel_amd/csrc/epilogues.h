@@ -78,6 +78,7 @@ struct EpiBias {
 
 // ---- input_proj: h = ((x W^T + b) + t_emb[t]) + c_proj   (models/diffusion.py:229-232) ----
 struct EpiInput {
+  static constexpr bool KSPLIT2 = true;            // launch.h: the two-wave-group variant of the LDS-DMA kernel is instantiated for it
   static constexpr bool COUNTED_STORES = true;
   static constexpr bool XBUF = false;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}
@@ -143,6 +144,7 @@ struct EpiInput {
 // (mean, rstd) for backward.
 template <int GW, bool DROP>
 struct EpiGnSilu {
+  static constexpr bool KSPLIT2 = GW == 32 || GW == 64;      // the widths of the BASELINE trunk (256 / 512): two-wave-group variant instantiated
   static constexpr bool COUNTED_STORES = true;
   static constexpr bool XBUF = false;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}

@@ -9,6 +9,7 @@ namespace osd {
 struct TrunkIn {
   const float* x; int ldx; int64_t n;
   float* in_slabs; int in_slices; // > 1: input_proj split-K over that many slices (k_fused.hip), slabs = in_slices x n x H0 floats
+  bool ksplit;                   // training-sized batches: ask for the two-wave-group GEMM variant (gemm_glds.h, NG = 2) in every layer
   bool a_unpacked;               // input_proj reads input_proj.weight itself (clamped at D, GemmArgs::a_kmax) instead of the packed copy;
                                  // x must then be zero in the columns [D, kx) (training: the library's own x_t buffer)
   int kx;                        // K extent of input_proj: 0 = D; Dp when x is the padded chain state (handle.h)

@@ -38,6 +38,7 @@ struct GemmArgs {
   int F, P, K;
   int kchunk;                  // gemm_kernel split-K: blockIdx.y reduces k in [y*kchunk, (y+1)*kchunk); 0 = no split
   int persist;                 // gemm_glds_kernel: persistent patient-tile walk (see gemm_glds.h)
+  int ksplit;                  // gemm_glds_kernel: 1 = the two-wave-group variant (NG = 2, see gemm_glds.h) where it is instantiated
   int a_kmax;                  // gemm_glds_kernel: > 0 = the A operand is only readable for k < a_kmax (an unpadded weight whose K is not a
                                // multiple of 32): its staging addresses are clamped there, and the B operand must hold ZEROS for
                                // k in [a_kmax, K) instead (a padded activation buffer owned by the library)

@@ -85,10 +85,21 @@ struct GldsTile {
 // lets a workgroup (a) fetch its per-feature epilogue parameters once, before the first K loop,
 // (b) issue the first DMA of the NEXT tile before the epilogue of the current one, and (c) leave the
 // epilogue's stores in flight instead of draining them before its slot is reused.
-template <class T, class Epi>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, typename Epi::Args ea) {
+//
+// NG = 2 ("two wave groups", training-sized batches): a layer of 4096 rows x 256 features is 256 tiles -- one workgroup per CU, one
+// wave per SIMD, and a lone wave cannot hide the barrier / wait / fragment-read latency of a K step (stamps: 1 660 cycles per step
+// for 1 024 cycles of MFMA at 64 x 64).  Here a workgroup has EIGHT waves: waves 4-7 are a second copy of the four tile waves with
+// their own staging buffers, and each group reduces one half of the K steps; at the end group 1 hands its accumulators to group 0
+// through LDS and leaves, group 0 adds them (first half + second half: a different fp32 summation order than NG = 1, so the
+// variant is opt-in per launch, GemmArgs::ksplit, and never used where the two sampling engines must agree bitwise) and runs the
+// epilogue.  Two waves per SIMD on all 256 CUs without needing 512 tiles.
+template <class T, class Epi, int NG = 1>
+__global__ __launch_bounds__(NTHREADS * NG, NG == 1 ? 2 : 1) void gemm_glds_kernel(GemmArgs g, typename Epi::Args ea) {
   typedef GldsTile<T> G;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(NG == 1 || NG == 2, "one or two wave groups");
+  extern __shared__ __attribute__((aligned(16))) float smem_all[];
+  const int grp = NG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));      // wave group of this wave
+  float* const smem = smem_all + grp * (G::LDS_BYTES / 4);
   float* As0 = smem;
   float* As1 = smem + G::A_ELEMS;
   float* Bs0 = smem + 2 * G::A_ELEMS;
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
   if (pt >= npt) return;
   const int f0 = ft * T::BF;
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & (NTHREADS - 1);       // position inside the wave group
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned long long st0 = 0, st1 = 0, st2 = 0;
@@ -217,10 +228,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
     }
   };
 
-  const int nk = (g.K + BK - 1) / BK;
+  const int nk_all = (g.K + BK - 1) / BK;
+  // NG = 2: group 0 reduces K steps [0, nk), group 1 [kbeg, kbeg + kcnt); both walk nk iterations (the barrier counts every wave)
+  const int nk = NG == 1 ? nk_all : (nk_all + 1) / 2;
+  const int kbeg = grp ? nk : 0;
+  const int kcnt = NG == 1 ? nk : (grp ? nk_all - nk : nk);
   // first K tile of the first patient tile
   {
-    const StageCtx c0 = stage_begin(0, pt * T::BP, As0, Bs0);
+    const StageCtx c0 = stage_begin(kbeg * BK, pt * T::BP, As0, Bs0);
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) stage_piece(c0, j);
   }
@@ -250,12 +265,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
     for (int kt = 0; kt < nk; ++kt) {
       float* Ac = (kt & 1) ? As1 : As0;
       float* Bc = (kt & 1) ? Bs1 : Bs0;
-      const bool more = kt + 1 < nk;
-      const StageCtx sc = stage_begin(more ? (kt + 1) * BK : 0, p0, (kt & 1) ? As0 : As1, (kt & 1) ? Bs0 : Bs1);
-      compute(Ac, Bc, 0, sc, more);
-      compute(Ac, Bc, 1, sc, more);
-      compute(Ac, Bc, 2, sc, more);
-      compute(Ac, Bc, 3, sc, more);
+      const bool more = kt + 1 < kcnt;
+      const StageCtx sc = stage_begin(more ? (kbeg + kt + 1) * BK : 0, p0, (kt & 1) ? As0 : As1, (kt & 1) ? Bs0 : Bs1);
+      if (NG == 1 || kt < kcnt) {            // uniform per wave group (group 1 may have one step less)
+        compute(Ac, Bc, 0, sc, more);
+        compute(Ac, Bc, 1, sc, more);
+        compute(Ac, Bc, 2, sc, more);
+        compute(Ac, Bc, 3, sc, more);
+      }
       // the DMA of K tile kt+1 had the MFMA block to land; publish it
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -268,6 +285,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_glds_kernel(GemmArgs g, type
       const StageCtx cn = stage_begin(0, ptn * T::BP, As0, Bs0);
 #pragma unroll
       for (int j = 0; j < NPIECE; ++j) stage_piece(cn, j);
+    }
+    if constexpr (NG == 2) {
+      // group 1's accumulators through its own staging buffers (free since the K loop's last barrier): [wave][register][lane]
+      constexpr int NREG = T::NFB * T::NPB * 16;
+      static_assert(4 * NREG * 64 * 4 <= G::LDS_BYTES, "accumulator hand-over must fit the group's staging buffers");
+      float* const red = smem_all + G::LDS_BYTES / 4 + wave * (NREG * 64);
+      if (grp == 1) {
+#pragma unroll
+        for (int i = 0; i < T::NFB; ++i)
+#pragma unroll
+          for (int j = 0; j < T::NPB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((i * T::NPB + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+      }
+      __syncthreads();
+      if (grp == 1) return;                  // uniform per wave; finished waves no longer count at the workgroup barrier
+#pragma unroll
+      for (int i = 0; i < T::NFB; ++i)
+#pragma unroll
+        for (int j = 0; j < T::NPB; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * T::NPB + j) * 16 + r) * 64 + lane];
     }
     counted_wait = Epi::COUNTED_STORES && (p0 + T::BP <= g.P) && (f0 + T::BF <= g.F);
     if constexpr (Epi::XBUF) {

@@ -97,6 +97,7 @@ struct osd_handle {
   // whose rows are padded to Dp = roundup(D, 4) floats, so that every operand is 16-byte aligned and the LDS-DMA / FAST tile code
   // and the chain kernel apply; the pad columns carry finite values that only ever meet zero weights
   int Dp = 0;
+  int train_ksplit = 1;              // osd_set_option("train_ksplit", 0|1): two wave groups per workgroup in the training forward's GEMMs (gemm_glds.h)
   int dual_dgrad = 1;                // osd_set_option("dual_dgrad", 0|1): a decoder block's two input dgrads in one launch (k_gnbwd.hip)
   int train_input_splitk = 0;        // osd_set_option("train_input_splitk"): K slices of input_proj in the training forward (0 / 1 = single pass)
   bool splitk_suspended = false;     // a chain-kernel fallback re-run in progress: no split-K (bit-identical to the chain kernel)

@@ -78,13 +78,17 @@ inline bool glds_ok(const GemmArgs& g, bool a_zero_padded) {
   return true;
 }
 
-template <class T, class Epi>
+template <class T, class Epi, int NG = 1>
 struct GldsRegistrar {
-  GldsRegistrar() { kernel_registry().push_back({reinterpret_cast<const void*>(gemm_glds_kernel<T, Epi>), GldsTile<T>::LDS_BYTES}); }
+  GldsRegistrar() { kernel_registry().push_back({reinterpret_cast<const void*>(gemm_glds_kernel<T, Epi, NG>), NG * GldsTile<T>::LDS_BYTES}); }
   static GldsRegistrar instance;
 };
-template <class T, class Epi>
-GldsRegistrar<T, Epi> GldsRegistrar<T, Epi>::instance;
+template <class T, class Epi, int NG>
+GldsRegistrar<T, Epi, NG> GldsRegistrar<T, Epi, NG>::instance;
+
+// which (tile, epilogue) pairs get the two-wave-group instantiation: the epilogue opts in (static constexpr bool KSPLIT2)
+template <class E, class = void> struct epi_ksplit2 : std::false_type {};
+template <class E> struct epi_ksplit2<E, std::void_t<decltype(E::KSPLIT2)>> : std::integral_constant<bool, E::KSPLIT2> {};
 
 int persist_mode();   // OSD_PERSIST env: 0 (default) one tile per workgroup; 1 / 2: persistent tile walk on 512 / 256 workgroups
 
@@ -93,6 +97,17 @@ hipError_t launch_gemm_glds(hipStream_t s, const GemmArgs& g0, const typename Ep
   (void)&GldsRegistrar<T, Epi>::instance;
   GemmArgs g = g0;
   int grid = gemm_grid(g.F, g.P, T::BF, T::BP);
+  if constexpr (epi_ksplit2<Epi>::value && T::BF * T::BP <= 64 * 128) {
+    // two wave groups: only worth it when the launch has about one tile per CU and a LONG K loop to split -- measured at the
+    // training batch: input_proj (63 K steps) 58 -> 49 us, the 1024-deep decoder layer 32 -> 28 us, but 8-16 K steps +-0 (the
+    // second group's prologue, the hand-over through LDS and its barrier cost what the shorter loop saves)
+    if (g.ksplit && grid <= 320 && g.K >= 32 * BK) {
+      (void)&GldsRegistrar<T, Epi, 2>::instance;
+      g.persist = 0;
+      hipLaunchKernelGGL((gemm_glds_kernel<T, Epi, 2>), dim3(grid), dim3(2 * NTHREADS), 2 * GldsTile<T>::LDS_BYTES, s, g, ea);
+      return hipGetLastError();
+    }
+  }
   // persistent patient-tile walk: 512 workgroups (2 per CU), each keeping one feature tile
   const int nft = (g.F + T::BF - 1) / T::BF;
   g.persist = 0;

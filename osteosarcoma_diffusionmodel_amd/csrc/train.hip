@@ -549,7 +549,7 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   OSD_TRY(cond_embed_fwd(h, s, cond, n, w));
   TrainWs& W = w;
   TrunkIn in{};
-  in.x = W.x_t; in.ldx = W.xld; in.kx = unpacked ? W.xld : D; in.a_unpacked = unpacked;
+  in.x = W.x_t; in.ldx = W.xld; in.kx = unpacked ? W.xld : D; in.a_unpacked = unpacked; in.ksplit = h->train_ksplit != 0;
   in.n = n; in.t_index = t_idx; in.train = train; in.save = grads != nullptr;
   in.masks = masks; in.seed = seed; in.row_offset = roff; in.drop_step = 0;
   // input_proj at the training batch: 256 output tiles of 63 sequential K steps, one workgroup per CU -- optionally K in slices
