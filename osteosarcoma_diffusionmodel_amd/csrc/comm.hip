@@ -113,11 +113,10 @@ int osd_comm_create(const void* id128, int rank, int world, int device, osd_comm
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   int rc = OSD_OK;
-  // highest priority: the collective's few workgroups (RCCL's ring kernels use a handful of CUs) must get onto the machine while
-  // the backward pass still fills it -- a default-priority stream queues behind the compute launches already dispatched
-  int prio_lo = 0, prio_hi = 0;
-  if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { prio_hi = 0; (void)hipGetLastError(); }
-  if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+  // default priority: a non-default stream priority upsets the hardware-queue assignment of this stack (measured with the torch
+  // binding on the 2-rank rehearsal: 6.3 -> 94-311 ms per step with a highest-priority comm stream; the low-priority side stream
+  // of train.hip slowed unrelated, later-created streams 3.3x) -- DESIGN.md section 7
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); rc = OSD_EHIP; }
   if (rc == OSD_OK) {
     const ncclResult_t r = api->CommInitRank(&c->comm, world, id, rank);
