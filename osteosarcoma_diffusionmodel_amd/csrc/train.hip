@@ -406,7 +406,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     GnBwdArgs ga{};
     ga.g = W.g_out[b]; ga.z = W.f.z2[b]; ga.stats = W.f.st2[b]; ga.gamma = h->params[l2.gamma]; ga.beta = h->params[l2.beta];
     ga.gz = W.g_z2[b]; ga.dgamma = grads[l2.gamma]; ga.dbeta = grads[l2.beta]; ga.dbias = grads[l2.b];
-    ga.rows = n; ga.C = C; ga.drop_mode = 0; ga.partials = W.partials; ga.atomic_cols = 1;
+    ga.rows = n; ga.C = C; ga.drop_mode = 0; ga.partials = W.partials; ga.atomic_cols = 0;      // fixed-order partial reduce: deterministic
     OSD_HIP(launch_gn_silu_bwd(s, l2.gw, ga));
     OSD_TRY(wg(W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C));
     OSD_HIP(dgrad(s, h->params[l2.w], C, C, W.g_z2[b], C, C, n, W.g_mid[b], C, false));
@@ -414,7 +414,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     GnBwdArgs gb{};
     gb.g = W.g_mid[b]; gb.z = W.f.z1[b]; gb.stats = W.f.st1[b]; gb.gamma = h->params[l1.gamma]; gb.beta = h->params[l1.beta];
     gb.gz = W.g_z1[b]; gb.dgamma = grads[l1.gamma]; gb.dbeta = grads[l1.beta]; gb.dbias = grads[l1.b];
-    gb.rows = n; gb.C = C; gb.partials = W.partials; gb.atomic_cols = 1;
+    gb.rows = n; gb.C = C; gb.partials = W.partials; gb.atomic_cols = 0;
     gb.drop_mode = drop ? (masks ? 1 : 2) : 0;
     gb.mask = (drop && masks) ? masks[b] : nullptr; gb.keep_scale = keep_scale; gb.p_drop = h->cfg.dropout_p;
     gb.seed = seed; gb.row_offset = roff; gb.step = 0; gb.tag = TAG_DROPOUT + (uint32_t)b;

@@ -552,6 +552,7 @@ class Trainer:
         self._comm_stream = None
         self._rccl = None
         self._engine = None if self.is_vae else self.model._engine()      # pointers = the flat buffer's views from here on
+        self._opts = self._option_state()
         self._ev_ptrs = None
         import os
         self.comm_kind = (comm or os.environ.get("OSD_COMM", "torch")).lower()
@@ -594,6 +595,10 @@ class Trainer:
                 logger.info("Dataset is resident in HBM: epochs replay the loader's batch order from device memory")
         return (self._resident_train, self._resident_val) if self.resident else (None, None)
 
+    def _option_state(self):
+        m = self.model
+        return tuple(getattr(m, k, None) for k in ("train_streams", "persistent_bwd", "sampler", "input_splitk"))
+
     def _bcast(self, t: torch.Tensor):
         """Broadcast from rank 0 in place (staged through the host when the backend is gloo)."""
         if torch.distributed.get_backend() == "nccl":
@@ -611,6 +616,12 @@ class Trainer:
         exposed (not overlapped) communication time of the step (bench.py)."""
         if not self.flat.is_current(quick=True):
             raise RuntimeError("model parameters were re-allocated after Trainer construction (e.g. model.to()); rebuild the Trainer")
+        if self._engine is not None and (self._engine.constraints_version != self.model._constraints_version or
+                                         self._opts != self._option_state()):
+            # set_constraints() or a tunable (train_streams, persistent_bwd, ...) changed after construction: let the model's own
+            # engine lookup re-apply them once (it also re-derives the tables), then keep using the fast path
+            self._engine = self.model._engine()
+            self._opts = self._option_state()
         if self.is_vae:
             # BiologyConstrainedVAE (utils/train.py:233-234): autograd over the HIP layer ops; gradients land in the
             # flat buffer's views, one all-reduce under data parallel, then the same fused clip + AdamW

@@ -363,3 +363,70 @@ def test_train_epoch_paths_give_the_reference_epoch(golden_dir, tmp_path, reside
         assert_close(sd1[k].cpu(), g["sd1." + k], 2e-5, atol=1e-8, what=f"param {k}")
     val = tr.validate()                       # the resident validation pass runs (4 batches of the same rows)
     assert np.isfinite(val)
+
+
+def test_fallback_groupnorm_backward_is_deterministic_and_trainer_follows_option_changes(tmp_path):
+    """(i) Block widths other than 256 / 512 (here 64 / 128: GroupNorm groups of 8 / 16 channels) take the stand-alone GroupNorm
+    backward kernel; its dgamma / dbeta / dbias come from a fixed-order partial reduce, so two passes over the same inputs agree bit
+    for bit (round-2 advisor finding: they were float atomics).  (ii) A tunable changed on the model after the Trainer was built
+    (here train_streams) reaches the Trainer's fast path."""
+    H = [64, 128, 64]
+    dims = dict(mutation_dim=8, expression_dim=48, pathway_dim=8, condition_dim=3)
+    conf = config(H)
+    conf["training"] = {"learning_rate": 1e-4, "weight_decay": 1e-5, "patience": 10, "min_delta": 1e-4, "augmentation": {"mixup_alpha": 0.0},
+                        "save_dir": str(tmp_path), "num_epochs": 1, "save_frequency": 10, "val_split": 0.2, "random_seed": 42, "batch_size": 512}
+    torch.manual_seed(3)
+    m = BiologyAwareDiffusionModel(config=conf, **dims).cuda().train()
+    gen = torch.Generator().manual_seed(1)
+    x, c = torch.randn(512, 64, generator=gen).cuda(), torch.randn(512, 3, generator=gen).cuda()
+    t, nz = torch.randint(0, 1000, (512,), generator=gen).cuda(), torch.randn(512, 64, generator=gen).cuda()
+    grads = []
+    for _ in range(2):
+        m.zero_grad()
+        m(x, c, t=t, noise=nz, seed=5).backward()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters()
+                      if k.startswith(("unet.encoder", "unet.decoder", "unet.bottleneck")) and
+                      k.endswith((".1.weight", ".1.bias", ".5.weight", ".5.bias", ".0.bias", ".4.bias"))})
+    assert grads[0] and all(torch.equal(grads[0][k], grads[1][k]) for k in grads[0])
+    tr = Trainer(m, [], [], conf, device="cuda")
+    tr.train_step(x, c, t=t, noise=nz, seed=5)
+    import ctypes as C
+    from osteosarcoma_diffusionmodel_amd import _lib as L
+    v = C.c_int64()
+    m.train_streams = 1
+    tr.train_step(x, c, t=t, noise=nz, seed=5)
+    L.check(L.lib().osd_get_option(tr._engine.handle, b"train_streams", C.byref(v)))
+    assert v.value == 1
+    m.train_streams = 2
+    tr.train_step(x, c, t=t, noise=nz, seed=5)
+    L.check(L.lib().osd_get_option(tr._engine.handle, b"train_streams", C.byref(v)))
+    assert v.value == 2
+
+
+def test_batch_source_with_constraint_losses(golden_dir):
+    """Rows from the resident dataset (osd_train_batch_source) while the constraint losses are configured: they read the mixed x0,
+    which the fused gather + mixup + q_sample kernel then also materialises -- loss and gradients must equal the call that is
+    handed the same mixed rows as tensors."""
+    m = small_model(golden_dir).train()
+    m.set_constraints(pathways=[[8, 9, 10, 11], [12, 13, 14]], mutation_columns=[0, 1], target_columns=[32, 33], pathway_weight=0.5, mutexpr_weight=0.25)
+    gen = torch.Generator().manual_seed(7)
+    N, B = 200, 64
+    data, cond = torch.randn(N, 40, generator=gen).cuda(), torch.randn(N, 3, generator=gen).cuda()
+    idx = torch.randperm(N, generator=gen)[:B].cuda()
+    perm = torch.randperm(B, generator=gen).cuda()
+    lam = 0.3
+    t, nz = torch.randint(0, 1000, (B,), generator=gen).cuda(), torch.randn(B, 40, generator=gen).cuda()
+    from osteosarcoma_diffusionmodel_amd.train import _loss_fwd_bwd, MixupAugmentation
+    mix = MixupAugmentation(0.2).mix({"data": data[idx], "conditions": cond[idx], "survival": torch.zeros(B, device="cuda")}, lam, perm)
+    ga = [torch.empty_like(p) for p in m.parameters()]
+    gb = [torch.empty_like(p) for p in m.parameters()]
+    la = _loss_fwd_bwd(m, mix["data"], mix["conditions"], L_ptrs(ga), t=t, noise=nz, seed=9)
+    lb = _loss_fwd_bwd(m, None, None, L_ptrs(gb), t=t, noise=nz, seed=9, source=(data, cond, idx, idx[perm], lam))
+    assert_close(lb.item(), la.item(), 1e-6, what="loss")
+    for (k, _), a, b in zip(m.named_parameters(), ga, gb):
+        assert_close(b.cpu(), a.cpu(), 1e-5, atol=1e-9, what=f"grad {k}")
+
+
+def L_ptrs(tensors):
+    from osteosarcoma_diffusionmodel_amd import _lib as L
+    return L.ptr_array(tensors)
