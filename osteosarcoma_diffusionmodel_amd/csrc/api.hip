@@ -669,7 +669,8 @@ static int chain_chunk(osd_handle* h, Slot& sl, const float* cond, int64_t n_tot
   {
     const int64_t tiles = (int64_t)((a.H0 + 63) / 64) * ((m + 63) / 64);
     if (h->input_splitk > 0 && !h->splitk_suspended) in_slices = h->input_splitk;
-    else if (h->input_splitk < 0 && !h->splitk_suspended && ldx >= 1024 && tiles < 128) in_slices = (int)std::min<int64_t>(16, std::max<int64_t>(2, 512 / tiles));
+    else if (h->input_splitk < 0 && !h->splitk_suspended && ldx >= 1024 && tiles < 384)      // fewer tiles than 1.5 per CU
+      in_slices = (int)std::min<int64_t>(16, std::max<int64_t>(2, (768 + tiles - 1) / tiles));
     in_slices = std::min(in_slices, ldx / 128);
     if (in_slices < 2) in_slices = 0;
   }
@@ -690,6 +691,7 @@ static int chain_chunk(osd_handle* h, Slot& sl, const float* cond, int64_t n_tot
   auto enqueue_step = [&](void) -> int {
     TrunkIn in{};
     in.x = x; in.ldx = ldx; in.kx = ldx; in.n = m; in.t_dev = sl.t_dev; in.in_slabs = in_slabs; in.in_slices = in_slices;
+    in.ksplit = in_slices > 1;             // the small-batch mode already trades bit-equality with the chain kernel for latency: long-K layers on two wave groups
     in.train = train; in.seed = seed; in.row_offset = roff; in.drop_step_dev = sl.t_dev;
     OSD_TRY(run_trunk(h, s, ws, in));
     GemmArgs g = output_proj_args(h, ws, m, padded);
