@@ -232,6 +232,7 @@ int refresh_derived(osd_handle* h, hipStream_t s, bool pack_in_w) {
   g.A = h->params[a.pm.tp_w]; g.lda = a.time_dim; g.B0 = h->d_time_emb; g.ldb0 = a.time_dim; g.K0 = a.time_dim;
   g.F = a.H0; g.P = a.T; g.K = a.time_dim;
   OSD_HIP(launch_linear(s, g, true, true, h->params[a.pm.tp_b], h->d_temb, a.H0, false, false));
+  h->panel_wpk_valid = false;           // the LDS-resident chain repacks its fragment-ordered copies before its next run
   if (!pack_in_w) return OSD_OK;        // a training step that reads input_proj.weight directly (the next osd_load_weights packs it)
   OSD_HIP(launch_copy2d(s, h->params[a.pm.in_w], a.D, h->w_in_packed, h->w_in_ld, a.H0, a.D));   // pad columns stay zero
   if (h->w_out_packed) {                       // D % 4 != 0: rows [D, Dp) stay zero
@@ -429,6 +430,11 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
     h->sampler = (int)value;
     return OSD_OK;
   }
+  if (!strcmp(name, "chain_variant")) {           // 0 auto, 1 workspace chain (chain.h), 2 LDS-resident chain (chain_panel.h) where the architecture fits
+    if (value < 0 || value > 2) { set_error("chain_variant must be 0 (auto), 1 (workspace chain) or 2 (LDS-resident chain)"); return OSD_EINVAL; }
+    h->chain_variant = (int)value;
+    return OSD_OK;
+  }
   if (!strcmp(name, "chain_grid")) {
     if (value < 0 || value > 65536) { set_error("chain_grid must be in [0,65536]"); return OSD_EINVAL; }
     h->chain_grid = (int)value;
@@ -517,7 +523,8 @@ int osd_get_option(osd_handle* h, const char* name, int64_t* value) {
       {"grouped_wgrad", h->grouped_wgrad}, {"fused_gn_bwd", h->fused_gn_bwd}, {"wgrad_mid_flush", h->wgrad_mid_flush},
       {"input_splitk", h->input_splitk}, {"train_streams", h->two_stream_bwd ? 2 : 1}, {"persistent_bwd", h->persistent_bwd}, {"bwd_spin_budget", (int64_t)h->bwd_spin_budget},
       // read-only counters
-      {"chain_fallbacks", h->chain_fallbacks}, {"last_engine", h->last_engine}};
+      {"chain_fallbacks", h->chain_fallbacks}, {"last_engine", h->last_engine},
+      {"chain_variant", h->chain_variant}, {"last_chain_variant", h->last_chain_variant}, {"panel_chain_supported", panel_chain_supported(h) ? 1 : 0}};
   for (const auto& e : tab)
     if (!strcmp(name, e.n)) { *value = e.v; return OSD_OK; }
   set_error("unknown option '%s'", name);

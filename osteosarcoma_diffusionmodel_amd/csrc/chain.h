@@ -109,12 +109,29 @@ __device__ __forceinline__ bool chain_wait(const unsigned* word, unsigned want, 
 // previous tile's epilogue), so no epilogue waits for a parameter load from L2 (stamps: two round trips of ~4 500 cycles each).
 constexpr int CHAIN_PRM_FLOATS = 512;
 
+// Where an epilogue's outputs go / its row-wise side input comes from.  The workspace chain (this file) turns every 32-feature
+// block through the wave's LDS transposer and moves full row segments to / from global memory; the LDS-resident chain
+// (chain_panel.h) writes the fragments straight into the next layer's operand panel.  The arithmetic around them is shared.
+template <int NPB>
+struct XposeRowsOut {
+  const WaveXpose<NPB>& xp; float* out; int ldo;
+  __device__ __forceinline__ void put(int fb, int pb, int q, int l31, int h, float4 v) const { (void)fb; xp.put(pb, q, l31, h, v); }
+  __device__ __forceinline__ void flush(int fb, int lane) const { xp.template store_rows<false>(out + 32 * fb, ldo, lane, 0, 0); }
+};
+template <int NPB>
+struct XposeRowsIn {
+  const WaveXpose<NPB>& xp; const float* src; int ld;
+  __device__ __forceinline__ void load(int fb, int lane) const { xp.template load_rows<false>(src + 32 * fb, ld, lane, 0, 0); }
+  __device__ __forceinline__ float4 get(int fb, int pb, int q, int l31, int h) const { (void)fb; return xp.get(pb, q, l31, h); }
+};
+
 // Linear -> GroupNorm(8) -> SiLU epilogue on a full private tile: the arithmetic of EpiGnSilu<GW, false>::apply, operation
 // for operation (the two engines agree bitwise).  `fl` = first feature of the wave inside the tile, `out` = row 0 of the
 // wave's rows at feature f0 + fl of the output buffer (all 128 rows exist: no guards).
-template <int GW, int NFB, int NPB>
-__device__ __forceinline__ void chain_gn_silu(f32x16 (&acc)[NFB][NPB], const float* __restrict__ prm, int fl, float* __restrict__ out, int ldo,
-                                              const WaveXpose<NPB>& xp, int lane, unsigned long long* ts = nullptr) {
+// PS = floats between the bias | gamma | beta arrays of the parameter block.
+template <int GW, int NFB, int NPB, int PS, class Out>
+__device__ __forceinline__ void chain_gn_silu(f32x16 (&acc)[NFB][NPB], const float* __restrict__ prm, int fl, const Out& o, int lane,
+                                              unsigned long long* ts = nullptr) {
   static_assert(GW >= 8 && NFB * 32 >= GW, "wave must own whole groups");
   constexpr int RPG = GW / 2;                 // registers of one group in this lane
   constexpr int NG = NFB * 16 / RPG;
@@ -154,8 +171,8 @@ __device__ __forceinline__ void chain_gn_silu(f32x16 (&acc)[NFB][NPB], const flo
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int f = fl + 32 * fb + 8 * q + 4 * h;
-      const float4 gv = *reinterpret_cast<const float4*>(prm + 128 + f);
-      const float4 bev = *reinterpret_cast<const float4*>(prm + 256 + f);
+      const float4 gv = *reinterpret_cast<const float4*>(prm + PS + f);
+      const float4 bev = *reinterpret_cast<const float4*>(prm + 2 * PS + f);
       const int g = (fb * 16 + 4 * q) / RPG;
 #pragma unroll
       for (int pb = 0; pb < NPB; ++pb) {
@@ -165,51 +182,52 @@ __device__ __forceinline__ void chain_gn_silu(f32x16 (&acc)[NFB][NPB], const flo
         y.y = silu_f(fmaf((acc[fb][pb][4 * q + 1] - m) * r, gv.y, bev.y));
         y.z = silu_f(fmaf((acc[fb][pb][4 * q + 2] - m) * r, gv.z, bev.z));
         y.w = silu_f(fmaf((acc[fb][pb][4 * q + 3] - m) * r, gv.w, bev.w));
-        xp.put(pb, q, l31, h, y);
+        o.put(fb, pb, q, l31, h, y);
       }
     }
-    xp.template store_rows<false>(out + 32 * fb, ldo, lane, 0, 0);
+    o.flush(fb, lane);
   }
 }
 
 // input_proj epilogue, EpiInput::apply's arithmetic: h = ((acc + b) + t_emb[t]) + c_proj.  The time-embedding row segment sits
 // in the gamma slot of the parameter block; cond_proj comes in (and h goes out) as full row segments through the transposer.
 // Rows beyond the valid ones of a partial tile hold finite copies (the host pads cproj to whole tiles) and stay private.
-template <int NFB, int NPB>
-__device__ __forceinline__ void chain_input(f32x16 (&acc)[NFB][NPB], const float* __restrict__ prm, int fl, const float* __restrict__ cproj, int ldc,
-                                            float* __restrict__ out, int ldo, const WaveXpose<NPB>& xp, int lane) {
+template <int NFB, int NPB, int PS, class In, class Out>
+__device__ __forceinline__ void chain_input(f32x16 (&acc)[NFB][NPB], const float* __restrict__ prm, int fl, const In& in, const Out& o, int lane) {
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int fb = 0; fb < NFB; ++fb) {
-    xp.template load_rows<false>(cproj + 32 * fb, ldc, lane, 0, 0);
+    in.load(fb, lane);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int f = fl + 32 * fb + 8 * q + 4 * h;
       const float4 bv = *reinterpret_cast<const float4*>(prm + f);
-      const float4 tv = *reinterpret_cast<const float4*>(prm + 128 + f);
+      const float4 tv = *reinterpret_cast<const float4*>(prm + PS + f);
 #pragma unroll
       for (int pb = 0; pb < NPB; ++pb) {
-        const float4 cv = xp.get(pb, q, l31, h);       // a lane reads and rewrites only its own fragment slots
+        const float4 cv = in.get(fb, pb, q, l31, h);   // a lane reads and rewrites only its own fragment slots
         float4 v;
         v.x = ((acc[fb][pb][4 * q] + bv.x) + tv.x) + cv.x;
         v.y = ((acc[fb][pb][4 * q + 1] + bv.y) + tv.y) + cv.y;
         v.z = ((acc[fb][pb][4 * q + 2] + bv.z) + tv.z) + cv.z;
         v.w = ((acc[fb][pb][4 * q + 3] + bv.w) + tv.w) + cv.w;
-        xp.put(pb, q, l31, h, v);
+        o.put(fb, pb, q, l31, h, v);
       }
     }
-    xp.template store_rows<false>(out + 32 * fb, ldo, lane, 0, 0);
+    o.flush(fb, lane);
   }
 }
 
 // output_proj + DDPM posterior update, EpiPosterior::apply's arithmetic: x' = A_t x + B_t (acc + b) + C_t z.  `x` = the wave's
 // first row at feature f0 + fl of the chain state (read and written in place: every element is read before this wave
 // overwrites it and no other wave touches it); prow / pcol = valid rows / features from there (<= 0: nothing to do).
-template <int NFB, int NPB>
+// PRE (chain_panel.h): the caller has already requested block 0's x_t rows into *pre (WaveXpose::issue_rows, same guards); every
+// block then requests the next one's rows before it computes, so no block waits for a global round trip.  Data movement only.
+template <int NFB, int NPB, bool PRE = false>
 __device__ __forceinline__ void chain_posterior(f32x16 (&acc)[NFB][NPB], const float* __restrict__ prm, int fl, float* __restrict__ x, int ldx,
                                                 int prow, int pcol, float cA, float cB, float cC, int t, const float* __restrict__ zrow, int ldzz,
                                                 uint64_t seed, uint32_t row_id0, int f_glob, float* __restrict__ mut_mask, int mutation_dim,
-                                                const WaveXpose<NPB>& xp, int lane) {
+                                                const WaveXpose<NPB>& xp, int lane, float4 (*pre)[4 * NPB] = nullptr) {
   const int l31 = lane & 31, h = lane >> 5;
   constexpr bool GUARD = true;                // a guard-free variant for full blocks was measured: +0.3 % (noise), 4 spills, +14 KB of code
   if (prow <= 0) return;                      // uniform over the wave
@@ -220,7 +238,12 @@ __device__ __forceinline__ void chain_posterior(f32x16 (&acc)[NFB][NPB], const f
     if (GUARD && cols <= 0) break;            // uniform
     // x_t of the block in row segments; a lane then reads and rewrites only its own fragment slots, so each get() can sit
     // right before its use (no 32-register copy of the block)
-    xp.template load_rows<GUARD>(x + 32 * fb, ldx, lane, prow, cols);
+    if constexpr (PRE) {
+      xp.commit_rows(*pre, lane);
+      if (fb + 1 < NFB && cols - 32 > 0) xp.template issue_rows<GUARD>(*pre, x + 32 * (fb + 1), ldx, lane, prow, cols - 32);
+    } else {
+      xp.template load_rows<GUARD>(x + 32 * fb, ldx, lane, prow, cols);
+    }
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) {
       const int p = 32 * pb + l31;            // row inside the wave's rows
@@ -603,13 +626,17 @@ __global__ __launch_bounds__(NTHREADS, CHAIN_WPS) void chain_kernel(const ChainA
         const ChainArgs& e = *ep;
         unsigned long long ets[3] = {0, 0, 0};
         if (L.kind == CK_GN64) {
-          chain_gn_silu<64, T::NFB, T::NPB>(acc, prm, wf, ws + L.out + (size_t)wp * L.ldo + fw, L.ldo, xp, lane, STAMP ? ets : nullptr);
+          const XposeRowsOut<T::NPB> o{xp, ws + L.out + (size_t)wp * L.ldo + fw, L.ldo};
+          chain_gn_silu<64, T::NFB, T::NPB, 128>(acc, prm, wf, o, lane, STAMP ? ets : nullptr);
         } else if (L.kind == CK_GN32) {
-          chain_gn_silu<32, T::NFB, T::NPB>(acc, prm, wf, ws + L.out + (size_t)wp * L.ldo + fw, L.ldo, xp, lane, STAMP ? ets : nullptr);
+          const XposeRowsOut<T::NPB> o{xp, ws + L.out + (size_t)wp * L.ldo + fw, L.ldo};
+          chain_gn_silu<32, T::NFB, T::NPB, 128>(acc, prm, wf, o, lane, STAMP ? ets : nullptr);
         } else if (L.kind == CK_INPUT) {
           // rows beyond P hold a clamped copy of the last valid row: computed and stored to the private tile like the others (the
           // host pads cproj to whole tiles), never published (the posterior epilogue stores rows < P only)
-          chain_input<T::NFB, T::NPB>(acc, prm, wf, e.cproj + (size_t)(p0 + wp) * e.ldc + fw, e.ldc, ws + L.out + (size_t)wp * L.ldo + fw, L.ldo, xp, lane);
+          const XposeRowsIn<T::NPB> ci{xp, e.cproj + (size_t)(p0 + wp) * e.ldc + fw, e.ldc};
+          const XposeRowsOut<T::NPB> o{xp, ws + L.out + (size_t)wp * L.ldo + fw, L.ldo};
+          chain_input<T::NFB, T::NPB, 128>(acc, prm, wf, ci, o, lane);
         } else {
           const float* c = e.coef + 4 * t;
           const float cA = c[0], cB = c[1], cC = c[2];

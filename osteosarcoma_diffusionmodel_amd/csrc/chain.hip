@@ -49,6 +49,17 @@ static int chain_device_limits(int device, int* max_grid) {
   return OSD_OK;
 }
 
+// which chain kernel: the workspace chain (chain.h) unless osd_set_option("chain_variant", 2) asks for the LDS-resident one
+// (chain_panel.h) and the architecture fits its panels.  Measured on MI355X (tools/probes/engine_sizes.py, D = 2000, M patient-steps/s):
+// n = 16 384: panel 20.9 / workspace 9.9 / per-layer 19.9; n = 32 768: 20.6 / 19.5 / 21.7; n = 100 000: 20.4 / 22.8 / 22.3 --
+// the LDS-resident kernel holds ~20.5 M from 16 384 rows on (every CU busy with 64-row units) but loses 11 % to the workspace
+// chain at the BASELINE size (one wave per SIMD pays every epilogue cycle in full), so it stays opt-in.
+static bool chain_use_panel(osd_handle* h, int64_t n) {
+  (void)n;
+  if (h->chain_variant != 2) return false;
+  return panel_chain_supported(h);
+}
+
 // 0 = per-layer kernels (eager or hipGraph), 1 = persistent chain kernel
 int chain_pick_engine(osd_handle* h, int64_t n, int flags) {
   if (h->sampler == 2) return 0;
@@ -64,13 +75,25 @@ int chain_pick_engine(osd_handle* h, int64_t n, int flags) {
   return n_tiles >= (int64_t)max_grid ? 1 : 0;
 }
 
-static int ensure_buf(float** p, int64_t* cap, int64_t floats, hipStream_t s) {
+int chain_ensure_buf(float** p, int64_t* cap, int64_t floats, hipStream_t s) {
   if (*cap >= floats) return OSD_OK;
   if (*p) { OSD_HIP(hipStreamSynchronize(s)); OSD_HIP(hipFree(*p)); *p = nullptr; *cap = 0; }
   void* q = nullptr;
   if (hipMalloc(&q, (size_t)floats * 4) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc of %lld bytes failed", (long long)floats * 4); return OSD_ENOMEM; }
   *p = (float*)q;
   *cap = floats;
+  return OSD_OK;
+}
+
+// sync words: [status, queue, pad x2 | cu arrivals x2048 | progress x n_tiles], zeroed before every chain
+int chain_ensure_sync(osd_handle* h, int64_t n_tiles, hipStream_t s) {
+  const int64_t words = 4 + 2048 + ((n_tiles + 3) / 4) * 4;
+  if (h->chain_sync_words < words) {
+    if (h->chain_sync) { OSD_HIP(hipStreamSynchronize(s)); OSD_HIP(hipFree(h->chain_sync)); h->chain_sync = nullptr; h->chain_sync_words = 0; }
+    if (hipMalloc((void**)&h->chain_sync, (size_t)words * 4) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc failed"); return OSD_ENOMEM; }
+    h->chain_sync_words = words;
+  }
+  OSD_HIP(hipMemsetAsync(h->chain_sync, 0, (size_t)words * 4, s));
   return OSD_OK;
 }
 
@@ -146,6 +169,11 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
   const int T = a.T, H0 = a.H0;
   hipStream_t s = h->stream;
   OSD_TRY(chain_check_status(h));
+  if (chain_use_panel(h, n)) {
+    h->last_chain_variant = 2;
+    return panel_chain_run(h, cond, n, x_T, noises, seed, row_offset, x_out, mut_mask_out);
+  }
+  h->last_chain_variant = 1;
   // D % 4 != 0: the kernel works on an internal copy of the state with rows of Dp = roundup(D, 4) floats (pad columns start at
   // zero, meet zero weights in input_proj and get zero eps from the packed output_proj) and the result is copied out at the end
   const bool padded = h->w_out_packed != nullptr;
@@ -198,13 +226,13 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
   std::vector<int> o_mid(a.n_blocks), o_out(a.n_blocks);
   for (int b = 0; b < a.n_blocks; ++b) { o_mid[b] = (int)boff[1 + 2 * b]; o_out[b] = (int)boff[2 + 2 * b]; }
   ca.ws_stride = off;
-  OSD_TRY(ensure_buf(&h->chain_ws, &h->chain_ws_floats, (int64_t)max_grid * off, s));
+  OSD_TRY(chain_ensure_buf(&h->chain_ws, &h->chain_ws_floats, (int64_t)max_grid * off, s));
   ca.ws = h->chain_ws;
 
   // ---- conditioning for all rows, hoisted out of the chain (loop-invariant in eval mode): ce1, ce2, cproj padded to whole tiles ----
   const int64_t rows_pad = (int64_t)n_tiles * BP;
   const int64_t c_off_ce2 = up64(n * 64), c_off_cp = c_off_ce2 + up64(n * 64);
-  OSD_TRY(ensure_buf(&h->chain_cond, &h->chain_cond_floats, c_off_cp + up64(rows_pad * H0), s));
+  OSD_TRY(chain_ensure_buf(&h->chain_cond, &h->chain_cond_floats, c_off_cp + up64(rows_pad * H0), s));
   FwdWs cw;
   cw.ce1 = h->chain_cond; cw.ce2 = h->chain_cond + c_off_ce2; cw.cproj = h->chain_cond + c_off_cp;
   OSD_TRY(run_cond(h, s, cond, n, cw));
@@ -213,21 +241,14 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
   // ---- x_T ----
   float* xs = x_state;
   if (padded) {
-    OSD_TRY(ensure_buf(&h->chain_xpad, &h->chain_xpad_floats, n * (int64_t)D, s));
+    OSD_TRY(chain_ensure_buf(&h->chain_xpad, &h->chain_xpad_floats, n * (int64_t)D, s));
     xs = h->chain_xpad;
     OSD_HIP(hipMemsetAsync(xs, 0, (size_t)n * D * 4, s));
   }
   if (x_T) OSD_HIP(launch_copy2d(s, x_T, a.D, xs, D, n, a.D));
   else OSD_HIP(launch_fill_randn(s, xs, D, n, a.D, seed, (uint32_t)row_offset, (uint32_t)T, TAG_POSTERIOR));
 
-  // ---- sync words: [status, queue, pad x2 | cu arrivals x2048 | progress x n_tiles], zeroed before every chain ----
-  const int64_t words = 4 + 2048 + ((n_tiles + 3) / 4) * 4;
-  if (h->chain_sync_words < words) {
-    if (h->chain_sync) { OSD_HIP(hipStreamSynchronize(s)); OSD_HIP(hipFree(h->chain_sync)); h->chain_sync = nullptr; h->chain_sync_words = 0; }
-    if (hipMalloc((void**)&h->chain_sync, (size_t)words * 4) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc failed"); return OSD_ENOMEM; }
-    h->chain_sync_words = words;
-  }
-  OSD_HIP(hipMemsetAsync(h->chain_sync, 0, (size_t)words * 4, s));
+  OSD_TRY(chain_ensure_sync(h, n_tiles, s));
   ca.status = h->chain_sync;
   ca.queue = h->chain_sync + 1;
   ca.cu_arrivals = h->chain_stagger > 0 ? h->chain_sync + 4 : nullptr;
@@ -335,6 +356,7 @@ void chain_free(osd_handle* h) {
   if (h->chain_sync) e = hipFree(h->chain_sync);
   if (h->chain_args_dev) e = hipFree(h->chain_args_dev);
   if (h->abort_stream) { e = hipStreamDestroy(h->abort_stream); h->abort_stream = nullptr; }
+  panel_chain_free(h);
   h->chain_args_dev = nullptr;
   free(h->chain_args_host);
   h->chain_args_host = nullptr;

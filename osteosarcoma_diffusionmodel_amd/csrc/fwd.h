@@ -37,6 +37,15 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
 int chain_check_status(osd_handle* h);
 int chain_finish(osd_handle* h, int* gave_up);
 void chain_free(osd_handle* h);
+int chain_ensure_buf(float** p, int64_t* cap, int64_t floats, hipStream_t s);
+int chain_ensure_sync(osd_handle* h, int64_t n_tiles, hipStream_t s);
+// chain_panel.hip
+bool panel_chain_supported(const osd_handle* h);
+int panel_chain_slots(osd_handle* h);
+int panel_chain_pack(osd_handle* h, hipStream_t s);
+int panel_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, const float* noises, uint64_t seed, int64_t row_offset,
+                    float* x_out, float* mut_mask_out);
+void panel_chain_free(osd_handle* h);
 // wgrad_group.hip
 struct WgPending;
 int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::vector<WgPending>& pend, float* slabs, int64_t slab_floats,

@@ -67,6 +67,24 @@ struct WaveXpose {
 #pragma unroll
     for (int i = 0; i < 4 * NPB; ++i) *reinterpret_cast<float4*>(buf + r * 32 + i * 256 + 4 * (cr ^ (i & 7))) = v[i];
   }
+  // load_rows in two halves, for a caller that has other work between the loads and their first use (chain_panel.h: a block's
+  // x_t rows are requested while the previous block is being computed)
+  template <bool GUARD>
+  __device__ __forceinline__ void issue_rows(float4 (&v)[4 * NPB], const float* __restrict__ g, int ld, int lane, int rows, int cols) const {
+    const int c = lane & 7, r = lane >> 3;
+#pragma unroll
+    for (int i = 0; i < 4 * NPB; ++i) {
+      int row = 8 * i + r;
+      int cc = 4 * c;
+      if (GUARD) { row = row < rows ? row : rows - 1; cc = cc < cols - 4 ? cc : cols - 4; }
+      v[i] = ldg4(g + (size_t)row * ld + cc);
+    }
+  }
+  __device__ __forceinline__ void commit_rows(const float4 (&v)[4 * NPB], int lane) const {
+    const int c = lane & 7, r = lane >> 3, cr = c ^ r;
+#pragma unroll
+    for (int i = 0; i < 4 * NPB; ++i) *reinterpret_cast<float4*>(buf + r * 32 + i * 256 + 4 * (cr ^ (i & 7))) = v[i];
+  }
 };
 
 }  // namespace osd

@@ -232,6 +232,11 @@ class BiologyAwareDiffusionModel(nn.Module):
         # reverse-chain engine: "auto" (library default: the persistent chain kernel for large eval-mode batches of a
         # 256/512-wide architecture, else the per-layer kernels), "chain", "graph" (per-layer kernels; hipGraph iff use_graph)
         self.sampler: str = "auto"
+        # which chain kernel: None / "auto" / "workspace" (csrc/chain.h: 128-row tiles, activations through a private workspace -- the
+        # faster one at the BASELINE size), "panel" (csrc/chain_panel.h: 64 patients per workgroup, activations in LDS; bit-identical,
+        # opt-in: it fills the chip from 16 384 rows on; architectures whose panels do not fit run the workspace kernel)
+        self.chain_variant: Optional[str] = None
+        self.last_chain_variant: Optional[str] = None     # the one the most recent chain-kernel sample() used
         self.chain_grid: Optional[int] = None             # workgroup count of the chain kernel (tests)
         self.chain_steps_per_launch: Optional[int] = None
         self.chain_stagger: Optional[int] = None
@@ -342,6 +347,11 @@ class BiologyAwareDiffusionModel(nn.Module):
         except KeyError:
             raise ValueError(f"sampler must be 'auto', 'chain' or 'graph', got {self.sampler!r}")
         L.check(L.lib().osd_set_option(eng.handle, b"sampler", mode))
+        try:
+            variant = {None: 0, "auto": 0, "workspace": 1, "panel": 2}[self.chain_variant]
+        except KeyError:
+            raise ValueError(f"chain_variant must be None, 'auto', 'workspace' or 'panel', got {self.chain_variant!r}")
+        L.check(L.lib().osd_set_option(eng.handle, b"chain_variant", variant))
         for name, val in (("chain_grid", self.chain_grid), ("chain_steps_per_launch", self.chain_steps_per_launch),
                           ("chain_stagger", self.chain_stagger), ("chain_spin_budget", self.chain_spin_budget),
                           ("chain_wall_budget_ms", self.chain_wall_budget_ms), ("input_splitk", self.input_splitk)):
@@ -484,6 +494,12 @@ class BiologyAwareDiffusionModel(nn.Module):
         if used < 0:
             L.check(used)
         self.last_sampler = "chain" if used == 1 else "graph"
+        self.last_chain_variant = None
+        if engine == 1:                      # which chain kernel ran (also set when its result was discarded for the re-run)
+            import ctypes as C
+            v = C.c_int64(0)
+            L.check(L.lib().osd_get_option(eng.handle, b"last_chain_variant", C.byref(v)))
+            self.last_chain_variant = {1: "workspace", 2: "panel"}.get(int(v.value))
         if engine == 1 and used != 1:
             import warnings
             warnings.warn(L.last_error() or "the reverse-chain kernel gave up; the chain was re-run on the per-layer kernels")

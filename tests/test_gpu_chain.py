@@ -34,28 +34,67 @@ def _model(T, hidden=FULL_H, seed=0, **dims):
     return m
 
 
-def _run(m, cond, n, sampler, **kw):
-    m.sampler = sampler
+def _run(m, cond, n, sampler, variant=None, **kw):
+    m.sampler, m.chain_variant = sampler, variant
     out, mask = m.sample(cond, n, return_mutation_mask=True, **kw)
     assert m.last_sampler == ("chain" if sampler == "chain" else "graph")
+    if sampler == "chain":
+        assert m.last_chain_variant == (variant or "workspace")
     return out, mask
 
 
+@pytest.mark.parametrize("variant", ["workspace", "panel"])
 @pytest.mark.parametrize("n,grid", [(1000, 3), (128, 1), (1337, 5), (4096, 0)])
-def test_chain_kernel_equals_per_layer_kernels_bitwise(n, grid):
+def test_chain_kernel_equals_per_layer_kernels_bitwise(n, grid, variant):
+    """Both chain kernels -- 128-row tiles through a workspace (csrc/chain.h) and 64 patients resident in LDS
+    (csrc/chain_panel.h: other tile shape, weights streamed from a fragment-ordered copy, activations never in global
+    memory) -- against the per-layer kernels, bit for bit."""
     T = 12
     m = _model(T)
     cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(3)).cuda()
     ref, ref_mask = _run(m, cond, n, "graph", seed=77, row_offset=5)
     m.chain_grid = grid
-    out, mask = _run(m, cond, n, "chain", seed=77, row_offset=5)
+    out, mask = _run(m, cond, n, "chain", variant, seed=77, row_offset=5)
     assert torch.isfinite(out).all()
     assert torch.equal(out, ref), f"max|d| = {(out - ref).abs().max().item():.3e} of {ref.abs().max().item():.3e}"
     assert torch.equal(mask, ref_mask)
     # segmented launches (progress carries over kernel boundaries) and no stagger: same bits
     m.chain_steps_per_launch, m.chain_stagger = 5, 0
-    out2, mask2 = _run(m, cond, n, "chain", seed=77, row_offset=5)
+    out2, mask2 = _run(m, cond, n, "chain", variant, seed=77, row_offset=5)
     assert torch.equal(out2, ref) and torch.equal(mask2, ref_mask)
+
+
+def test_panel_chain_vs_oracle_injected_draws_and_unaligned_dims():
+    """The LDS-resident chain kernel against the CPU oracle (injected x_T / z: 200 rows = three 64-patient units + 8 rows, T = 20),
+    then at the reference's real dims 62/5054/26 (D = 5142, D % 4 = 2: padded state, eleven output passes) against the per-layer
+    kernels bit for bit, and on an architecture whose panels do not fit (it must run the workspace kernel instead)."""
+    T, n = 20, 200
+    m = _model(T, seed=6)
+    gen = torch.Generator().manual_seed(11)
+    cond = torch.randn(n, 3, generator=gen)
+    x_T = torch.randn(n, 2000, generator=gen)
+    zs = torch.randn(T - 1, n, 2000, generator=gen)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items() if k.startswith(("condition_embed", "unet"))}
+    ref = O.sample(sd, O.schedule_buffers("cosine", T), cond, x_T, lambda t: zs[T - 1 - t], 3, 128)
+    m.chain_grid = 3
+    out, _ = _run(m, cond.cuda(), n, "chain", "panel", x_T=x_T.cuda(), noise=zs.cuda())
+    assert_close(out, ref, 5e-5, atol=1e-5, what="LDS-resident chain kernel vs oracle")
+
+    m2 = _model(6, seed=2, mutation_dim=62, expression_dim=5054, pathway_dim=26, condition_dim=4)
+    n2 = 150
+    cond2 = torch.randn(n2, 4, generator=gen).cuda()
+    ref2, refm2 = _run(m2, cond2, n2, "graph", seed=9)
+    m2.chain_grid = 2
+    out2, mask2 = _run(m2, cond2, n2, "chain", "panel", seed=9)
+    assert torch.equal(out2, ref2) and torch.equal(mask2, refm2)
+
+    m3 = _model(4, hidden=[512, 512, 512], seed=3)          # H0 = 512: no LDS-resident layout
+    cond3 = torch.randn(130, 3, generator=gen).cuda()
+    ref3, _ = _run(m3, cond3, 130, "graph", seed=1)
+    m3.sampler, m3.chain_variant = "chain", "panel"
+    out3 = m3.sample(cond3, 130, seed=1)
+    assert m3.last_sampler == "chain" and m3.last_chain_variant == "workspace"
+    assert torch.equal(out3, ref3)
 
 
 def test_chain_kernel_vs_oracle_with_injected_draws():
