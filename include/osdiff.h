@@ -91,12 +91,14 @@ int osd_set_stream(osd_handle *h, void *hip_stream);
  * between the starts of the two workgroups of a CU), "train_streams" (1 | 2: weight-gradient leaves on a side stream),
  * "grouped_wgrad" (1: every weight gradient of a backward pass in one grouped launch), "wgrad_mid_flush" (1: the decoder
  * half's weight gradients already mid-pass; always on under data parallel), "fused_gn_bwd" (1: GroupNorm backward inside
- * the dgrad epilogue), "chain_variant" (which chain kernel: 0 auto / 1 the workspace chain, 128-row tiles whose activations
- * pass through a private workspace -- the faster one at the BASELINE size; 2 the LDS-resident chain, 64 patients per workgroup
+ * the dgrad epilogue), "chain_variant" (which chain kernel: 1 the workspace chain, 128-row tiles whose activations
+ * pass through a private workspace -- the faster one from 65 536 rows on; 2 the LDS-resident chain, 64 patients per workgroup
  * with every activation in LDS, bit-identical, for architectures whose panels fit -- hidden_dims[0] = 256 = the last block's
- * width --, others fall back to 1; it fills the chip from 16 384 rows on), "dual_dgrad" / "train_ksplit" /
+ * width --, others fall back to 1; it fills the chip from 14 336 rows on; 0 auto: 1 for large batches, 2 for mid-size batches
+ * that would leave the per-layer kernels' last round of 128 x 128 tiles less than 93 % full), "dual_dgrad" / "train_ksplit" /
  * "train_input_splitk" / "persistent_bwd" (training-step experiments).  Auto sampler: the chain kernel when the batch has at least as many 128-row tiles as the device
- * holds resident workgroups (65 536 rows on an MI355X) and the model is in eval mode, else the per-layer kernels. */
+ * holds resident workgroups (65 536 rows on an MI355X) or falls into the LDS-resident kernel's window (above), and the model is
+ * in eval mode; else the per-layer kernels. */
 int osd_set_option(osd_handle *h, const char *name, int64_t value);
 
 /* Reads an option back, or one of the read-only counters "chain_fallbacks" (chains that gave up -- see osd_sample_chain --

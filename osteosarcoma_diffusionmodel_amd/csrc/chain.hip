@@ -49,15 +49,43 @@ static int chain_device_limits(int device, int* max_grid) {
   return OSD_OK;
 }
 
-// which chain kernel: the workspace chain (chain.h) unless osd_set_option("chain_variant", 2) asks for the LDS-resident one
-// (chain_panel.h) and the architecture fits its panels.  Measured on MI355X (tools/probes/engine_sizes.py, D = 2000, M patient-steps/s):
-// n = 16 384: panel 20.9 / workspace 9.9 / per-layer 19.9; n = 32 768: 20.6 / 19.5 / 21.7; n = 100 000: 20.4 / 22.8 / 22.3 --
-// the LDS-resident kernel holds ~20.5 M from 16 384 rows on (every CU busy with 64-row units) but loses 11 % to the workspace
-// chain at the BASELINE size (one wave per SIMD pays every epilogue cycle in full), so it stays opt-in.
+// Which chain kernel.  Measured on MI355X (tools/probes/engine_sizes.py, D = 2000, T = 200, M patient-steps/s):
+//   rows      per-layer   workspace chain   LDS-resident chain
+//   12 288      16.0           7.5               16.0
+//   16 384      20.0          10.0               21.1
+//   18 432      15.0          11.1               20.9
+//   24 576      18.9          14.7               20.7
+//   30 720      20.6          18.3               20.3
+//   36 864      18.7          17.9               20.3
+//   49 152      21.9          19.2               20.6
+//   65 536      22.3          22.1               20.4
+//  100 000      22.3          22.8               20.4
+// The LDS-resident kernel (chain_panel.h) holds ~20.5 M from 14 336 rows on -- 64-row units keep every CU busy -- but pays every
+// epilogue cycle in full (one wave per SIMD) and loses 11 % to the workspace chain where that one has a
+// tile for each of its 512 slots.  The per-layer kernels are fast exactly where their 128 x 128 tiles fill whole rounds of the
+// 512 slots (multiples of 16 384 rows at the 512-wide layers) and lose up to 28 % in between.  auto therefore takes the
+// LDS-resident kernel for mid-size batches that leave the per-layer kernels' last round under 93 % full.
+static bool panel_window(osd_handle* h, int64_t n) {
+  if (!panel_chain_supported(h)) return false;
+  const int slots = panel_chain_slots(h);
+  if (slots < 1) return false;
+  const int64_t units = (n + 63) / 64;
+  if (units * 8 < (int64_t)slots * 7) return false;           // fewer 64-row units than 7/8 of the CUs
+  int wide = 0;
+  for (int c : h->arch.block_out) wide = std::max(wide, c);
+  const int64_t tiles = ((n + 127) / 128) * ((wide + 127) / 128);      // the per-layer engine's tiles of a widest layer
+  const int64_t round = 2 * (int64_t)slots;                            // two workgroups per CU there
+  const int64_t rounds = (tiles + round - 1) / round;
+  return tiles * 100 < rounds * round * 93;
+}
+
 static bool chain_use_panel(osd_handle* h, int64_t n) {
-  (void)n;
-  if (h->chain_variant != 2) return false;
-  return panel_chain_supported(h);
+  if (h->chain_variant == 1) return false;
+  if (h->chain_variant == 2) return panel_chain_supported(h);
+  int max_grid = 0;
+  if (chain_device_limits(h->cfg.device, &max_grid) != OSD_OK) return false;
+  if ((n + ChainTile::BP - 1) / ChainTile::BP >= (int64_t)max_grid) return false;       // the workspace chain has a tile per slot
+  return panel_window(h, n);
 }
 
 // 0 = per-layer kernels (eager or hipGraph), 1 = persistent chain kernel
@@ -69,10 +97,12 @@ int chain_pick_engine(osd_handle* h, int64_t n, int flags) {
   int max_grid = 0;
   if (chain_device_limits(h->cfg.device, &max_grid) != OSD_OK || max_grid < 2) return 0;
   const int64_t n_tiles = (n + ChainTile::BP - 1) / ChainTile::BP;
-  // every slot gets a tile: with fewer tiles than resident workgroups the chain kernel idles CUs (384 tiles: 19.4 M
+  // every slot gets a tile: with fewer tiles than resident workgroups the workspace chain idles CUs (384 tiles: 19.4 M
   // patient-steps/s against 21.8 M for the per-layer engine, which also tiles the features; 512 tiles: 22.2 vs 22.1; beyond
-  // that the chain kernel leads -- tools/probes/engine_crossover.py)
-  return n_tiles >= (int64_t)max_grid ? 1 : 0;
+  // that the chain kernel leads -- tools/probes/engine_crossover.py); below that, the LDS-resident chain where it leads
+  if (n_tiles >= (int64_t)max_grid) return 1;
+  if (h->chain_variant != 1 && panel_window(h, n)) return 1;
+  return 0;
 }
 
 int chain_ensure_buf(float** p, int64_t* cap, int64_t floats, hipStream_t s) {

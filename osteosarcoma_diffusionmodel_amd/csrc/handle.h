@@ -157,7 +157,7 @@ struct osd_handle {
   unsigned long long* chain_stamps = nullptr;   // diagnostic builds (csrc/diag): device buffer of 8 counters per workgroup, else null
   int last_engine = 0;               // engine of the most recent osd_sample_chain (0 per-layer, 1 chain kernel)
   // LDS-resident variant of the chain kernel (chain_panel.h / chain_panel.hip)
-  int chain_variant = 0;             // osd_set_option("chain_variant"): 0 auto (= 1 today), 1 workspace chain (chain.h), 2 LDS-resident chain where the architecture fits (else 1)
+  int chain_variant = 0;             // osd_set_option("chain_variant"): 0 auto (chain.hip: chain_use_panel), 1 workspace chain (chain.h), 2 LDS-resident chain where the architecture fits (else 1)
   int last_chain_variant = 0;        // variant the most recent chain-kernel run used (osd_get_option)
   float* panel_wpk = nullptr; int64_t panel_wpk_floats = 0;   // fragment-ordered copies of the weights
   bool panel_wpk_valid = false;      // false after anything that may have changed the parameters: repacked by the next chain

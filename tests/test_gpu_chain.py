@@ -64,6 +64,21 @@ def test_chain_kernel_equals_per_layer_kernels_bitwise(n, grid, variant):
     assert torch.equal(out2, ref) and torch.equal(mask2, ref_mask)
 
 
+def test_auto_takes_the_lds_resident_chain_for_mid_size_batches():
+    """auto: 18 432 rows are 288 units of 64 patients (every CU busy) but 1.125 rounds of the per-layer kernels' tiles -- the
+    LDS-resident chain runs, with the per-layer kernels' bits; 2 048 rows stay on the per-layer kernels."""
+    T, n = 3, 18432
+    m = _model(T, seed=8)
+    cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(5)).cuda()
+    ref, ref_mask = _run(m, cond, n, "graph", seed=31)
+    m.sampler, m.chain_variant = "auto", None
+    out, mask = m.sample(cond, n, return_mutation_mask=True, seed=31)
+    assert (m.last_sampler, m.last_chain_variant) == ("chain", "panel")
+    assert torch.equal(out, ref) and torch.equal(mask, ref_mask)
+    m.sample(cond[:2048], 2048, seed=31)
+    assert m.last_sampler == "graph"
+
+
 def test_panel_chain_vs_oracle_injected_draws_and_unaligned_dims():
     """The LDS-resident chain kernel against the CPU oracle (injected x_T / z: 200 rows = three 64-patient units + 8 rows, T = 20),
     then at the reference's real dims 62/5054/26 (D = 5142, D % 4 = 2: padded state, eleven output passes) against the per-layer
@@ -221,7 +236,8 @@ def test_chain_spin_timeout_is_recovered_on_the_per_layer_kernels():
     assert torch.equal(out3, ref2) and _get_option(m, "chain_fallbacks") == 2
 
 
-def test_chain_wall_clock_budget_aborts_and_recovers():
+@pytest.mark.parametrize("variant", ["workspace", "panel"])
+def test_chain_wall_clock_budget_aborts_and_recovers(variant):
     """The host side of the same guarantee: a synchronous chain is polled (hipStreamQuery) against a wall-clock budget instead
     of a blind hipStreamSynchronize; on expiry the host raises the abort flag, the workgroups leave at their next unit
     boundary / dependency poll, and the chain is re-run on the per-layer kernels.  Budget 1 ms against a chain of ~50 ms."""
@@ -229,13 +245,13 @@ def test_chain_wall_clock_budget_aborts_and_recovers():
     m = _model(T, seed=8)
     cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(1)).cuda()
     ref, ref_mask = _run(m, cond, n, "graph", seed=5)
-    m.sampler, m.chain_wall_budget_ms = "chain", 1
+    m.sampler, m.chain_variant, m.chain_wall_budget_ms = "chain", variant, 1
     with pytest.warns(UserWarning):
         out, mask = m.sample(cond, n, seed=5, return_mutation_mask=True)
-    assert m.last_sampler == "graph" and _get_option(m, "chain_fallbacks") == 1
+    assert m.last_sampler == "graph" and m.last_chain_variant == variant and _get_option(m, "chain_fallbacks") == 1
     assert torch.equal(out, ref) and torch.equal(mask, ref_mask)
     m.chain_wall_budget_ms = 0                  # automatic budget (10 x the estimate + 2 s): the chain kernel finishes
-    out2, _ = _run(m, cond, n, "chain", seed=5)
+    out2, _ = _run(m, cond, n, "chain", variant, seed=5)
     assert torch.equal(out2, ref) and _get_option(m, "chain_fallbacks") == 1
 
 

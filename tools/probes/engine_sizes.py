@@ -10,7 +10,8 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 torch.manual_seed(0)
 m = BiologyAwareDiffusionModel(config=config(FULL_H, T=T), **FULL).cuda().eval()
 m.input_splitk = 0
-for n in (8192, 16384, 24576, 32768, 49152, 65536, 100000, 131072):
+sizes = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else (8192, 16384, 24576, 32768, 49152, 65536, 100000, 131072)
+for n in sizes:
     cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(3)).cuda()
     row = []
     for name, sampler, variant in (("per-layer", "graph", None), ("workspace", "chain", "workspace"), ("panel", "chain", "panel")):
