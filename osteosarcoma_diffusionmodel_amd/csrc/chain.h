@@ -221,6 +221,9 @@ __device__ __forceinline__ void chain_input(f32x16 (&acc)[NFB][NPB], const float
 // output_proj + DDPM posterior update, EpiPosterior::apply's arithmetic: x' = A_t x + B_t (acc + b) + C_t z.  `x` = the wave's
 // first row at feature f0 + fl of the chain state (read and written in place: every element is read before this wave
 // overwrites it and no other wave touches it); prow / pcol = valid rows / features from there (<= 0: nothing to do).
+#ifndef OSD_EXP
+#define OSD_EXP 0      // timing experiments only (make CXXFLAGS+=-DOSD_EXP=n, garbage results): 1 no Philox / Box-Muller, 2 no x_t loads, 4 no stores
+#endif
 // PRE (chain_panel.h): the caller has already requested block 0's x_t rows into *pre (WaveXpose::issue_rows, same guards); every
 // block then requests the next one's rows before it computes, so no block waits for a global round trip.  Data movement only.
 template <int NFB, int NPB, bool PRE = false>
@@ -239,8 +242,10 @@ __device__ __forceinline__ void chain_posterior(f32x16 (&acc)[NFB][NPB], const f
     // x_t of the block in row segments; a lane then reads and rewrites only its own fragment slots, so each get() can sit
     // right before its use (no 32-register copy of the block)
     if constexpr (PRE) {
-      xp.commit_rows(*pre, lane);
-      if (fb + 1 < NFB && cols - 32 > 0) xp.template issue_rows<GUARD>(*pre, x + 32 * (fb + 1), ldx, lane, prow, cols - 32);
+      if (!(OSD_EXP & 2)) {
+        xp.commit_rows(*pre, lane);
+        if (fb + 1 < NFB && cols - 32 > 0) xp.template issue_rows<GUARD>(*pre, x + 32 * (fb + 1), ldx, lane, prow, cols - 32);
+      }
     } else {
       xp.template load_rows<GUARD>(x + 32 * fb, ldx, lane, prow, cols);
     }
@@ -260,7 +265,7 @@ __device__ __forceinline__ void chain_posterior(f32x16 (&acc)[NFB][NPB], const f
           if (zrow) {
             const int fc = (!GUARD || fo < pcol - 4) ? fo : pcol - 4;
             zz = ldg4(zrow + (size_t)pc * ldzz + fc);
-          } else {
+          } else if (!(OSD_EXP & 1)) {
             zz = randn4(seed, row_id0 + (uint32_t)p, (uint32_t)((f_glob + fo) >> 2), (uint32_t)t, TAG_POSTERIOR);
           }
         }
@@ -277,7 +282,7 @@ __device__ __forceinline__ void chain_posterior(f32x16 (&acc)[NFB][NPB], const f
         xp.put(pb, q, l31, h, make_float4(o[0], o[1], o[2], o[3]));
       }
     }
-    xp.template store_rows<GUARD>(x + 32 * fb, ldx, lane, prow, cols);
+    if (!(OSD_EXP & 4)) xp.template store_rows<GUARD>(x + 32 * fb, ldx, lane, prow, cols);
   }
 }
 

@@ -51,32 +51,28 @@ static int chain_device_limits(int device, int* max_grid) {
 
 // Which chain kernel.  Measured on MI355X (tools/probes/engine_sizes.py, D = 2000, T = 200, M patient-steps/s):
 //   rows      per-layer   workspace chain   LDS-resident chain
-//   12 288      16.0           7.5               16.0
-//   16 384      20.0          10.0               21.1
-//   18 432      15.0          11.1               20.9
-//   24 576      18.9          14.7               20.7
-//   30 720      20.6          18.3               20.3
-//   36 864      18.7          17.9               20.3
-//   49 152      21.9          19.2               20.6
-//   65 536      22.3          22.1               20.4
-//  100 000      22.3          22.8               20.4
-// The LDS-resident kernel (chain_panel.h) holds ~20.5 M from 14 336 rows on -- 64-row units keep every CU busy -- but pays every
-// epilogue cycle in full (one wave per SIMD) and loses 11 % to the workspace chain where that one has a
-// tile for each of its 512 slots.  The per-layer kernels are fast exactly where their 128 x 128 tiles fill whole rounds of the
-// 512 slots (multiples of 16 384 rows at the 512-wide layers) and lose up to 28 % in between.  auto therefore takes the
-// LDS-resident kernel for mid-size batches that leave the per-layer kernels' last round under 93 % full.
+//    8 192      17.8           5.0               11.4
+//   10 240      13.9           6.3               14.3
+//   12 288      16.2           7.6               17.1
+//   16 384      20.1           9.9               22.5
+//   20 480      16.4          12.3               22.6
+//   28 672      19.6          17.1               22.3
+//   32 768      21.7          19.5               22.4
+//   49 152      21.9          19.7               22.4
+//   65 536      22.2          22.5               22.4
+//   81 920      22.3          23.0               22.4
+//   98 304      22.5          23.0               22.4
+// The LDS-resident kernel (chain_panel.h) runs at 22.4 M from 16 384 rows on -- 64-row units keep every CU busy and its queue has
+// no step boundary -- where the per-layer kernels are fast only at whole rounds of their 128 x 128 tiles (multiples of 16 384
+// rows) and the workspace chain needs a 128-row tile for each of its 512 slots; from there on the workspace chain leads by
+// 1-2.5 % (two independent workgroups per CU hide each other's epilogues).  auto: workspace chain from
+// 512 tiles on, LDS-resident chain from 5/8 of the CUs' worth of units (10 240 rows), per-layer kernels below.
 static bool panel_window(osd_handle* h, int64_t n) {
   if (!panel_chain_supported(h)) return false;
   const int slots = panel_chain_slots(h);
   if (slots < 1) return false;
   const int64_t units = (n + 63) / 64;
-  if (units * 8 < (int64_t)slots * 7) return false;           // fewer 64-row units than 7/8 of the CUs
-  int wide = 0;
-  for (int c : h->arch.block_out) wide = std::max(wide, c);
-  const int64_t tiles = ((n + 127) / 128) * ((wide + 127) / 128);      // the per-layer engine's tiles of a widest layer
-  const int64_t round = 2 * (int64_t)slots;                            // two workgroups per CU there
-  const int64_t rounds = (tiles + round - 1) / round;
-  return tiles * 100 < rounds * round * 93;
+  return units * 8 >= (int64_t)slots * 5;
 }
 
 static bool chain_use_panel(osd_handle* h, int64_t n) {

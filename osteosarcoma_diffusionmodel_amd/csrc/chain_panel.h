@@ -33,6 +33,17 @@
 namespace osd {
 
 constexpr int PC_BP = 64;                         // patients per unit
+#ifndef PC_NW
+#define PC_NW 8
+#endif
+// Waves per workgroup.  8 (two per SIMD): a wave owns F/8 output features x all 64 patients, i.e. the 64 x 64 accumulator of the
+// tile kernels for 512-wide layers and 32 x 64 for 256-wide ones; the second wave of a SIMD fills the first one's LDS / memory /
+// transcendental latencies and MFMA issue bubbles (one wave per SIMD: 72 cycles per 64-cycle MFMA in the K loops and every
+// epilogue stall paid in full -- profiles/r03_chain_panel.md).  4 (make CXXFLAGS+=-DPC_NW=4) is the first version, kept as a build option.
+constexpr int PC_THREADS = 64 * PC_NW;
+constexpr int PC_NFB_WIDE = 512 / (32 * PC_NW);   // feature blocks per wave: 512-wide layers and output_proj passes
+constexpr int PC_NFB_NARROW = 256 / (32 * PC_NW); // 256-wide layers and input_proj
+static_assert(PC_NW == 4 || PC_NW == 8, "4 or 8 waves");
 constexpr int PC_N8_MIN = 16;                     // 8-k blocks of a K segment: a multiple of 8, at least 16 (two groups of the 64-feature waves' weight stream)
 constexpr int PC_CHUNK = 256;                     // k per staged chunk of x_t
 constexpr int PC_HALF = PC_BP * (PC_CHUNK + 4);   // floats of one chunk buffer [64][260]
@@ -84,11 +95,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) v4f* gv4f_ptr;
 
 // ---- the weight stream ----------------------------------------------------------------------------------------------------
-// A lane keeps PC_SLOTS float4 registers of weights in flight: DEPTH = 16 / NFB 8-k blocks ahead of the MFMAs (8 blocks for the
-// 64-feature waves of the 256-wide layers, 4 for the 128-feature waves), slot j = d * NFB + fb.  The stream never stops: the last
+// A lane keeps PC_SLOTS float4 registers of weights in flight: DEPTH = PC_SLOTS / NFB 8-k blocks ahead of the MFMAs (8 blocks in the
+// 256-wide layers, 4 in the 512-wide ones), slot j = d * NFB + fb.  The stream never stops: the last
 // group of a K segment refills its slots from whatever comes next -- the same layer's next segment, the next layer, the next
 // output_proj pass, the next unit's input_proj -- so the only exposed round trip of a workgroup is its very first one.
-constexpr int PC_SLOTS = 16;
+constexpr int PC_SLOTS = 64 / PC_NW;     // 16 float4 per lane with four waves, 8 with eight (256 registers per wave)
 struct WStream {
   gv4f_ptr w;       // the lane's pointer at (feature block 0 of its wave, 8-k block 0)
   int fbs;          // float4s between feature blocks
@@ -146,13 +157,17 @@ __device__ __forceinline__ void panel_kseg(f32x16 (&acc)[NFB][2], v4f (&aq)[PC_S
   for (; i0 < n8 - DEPTH; i0 += DEPTH) group(i0, true, false);
   group(i0, false, false);
 }
+#if PC_NW == 4
 #define PC_WAIT_DMA() asm volatile("s_waitcnt vmcnt(16)" ::: "memory")
+#else
+#define PC_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#endif
 // Workgroup barrier for LDS traffic only.  __syncthreads() is a workgroup-scope release/acquire over ALL address spaces: hipcc
 // puts s_waitcnt vmcnt(0) in front of it, which drains the weight stream's prefetch at every barrier (measured: the round trip
 // then shows up in the epilogues instead of the K loops).  Everything the barriers of this kernel order is LDS -- panels,
 // parameters, flags; DMA pieces are waited for explicitly (PC_WAIT_DMA), global hand-offs have their own fences.
 #define PC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-static_assert(PC_SLOTS == 16, "PC_WAIT_DMA counts the slots");
+static_assert(PC_SLOTS == (PC_NW == 4 ? 16 : 8), "PC_WAIT_DMA counts the slots");
 
 template <int NFB>
 __device__ __forceinline__ void panel_zero(f32x16 (&acc)[NFB][2]) {
@@ -188,7 +203,7 @@ struct PanelIn {
 };
 
 template <bool STAMP>
-__global__ __launch_bounds__(NTHREADS, 1) void panel_chain_kernel(const PanelArgs* __restrict__ gp) {
+__global__ __launch_bounds__(PC_THREADS, 1) void panel_chain_kernel(const PanelArgs* __restrict__ gp) {
   const PanelArgs& a = *gp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const region = smem;
@@ -214,11 +229,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel_chain_kernel(const PanelArg
     glds16(src + k, __builtin_amdgcn_readfirstlane(lds_addr(dst)));
   };
 
-  // the wave's weight stream of a layer (input_proj / GroupNorm layers: F / 4 features per wave; output_proj: pass 0)
+  // the wave's weight stream of a layer (input_proj / GroupNorm layers: F / PC_NW features per wave; output_proj: pass 0)
   auto layer_stream = [&](const PanelLayer& Ls) {
-    const int nfb = Ls.kind == CK_POST ? 4 : Ls.F / 128;
+    const int nfb = (Ls.kind == CK_POST || Ls.F == 512) ? PC_NFB_WIDE : PC_NFB_NARROW;
     const int fbs = Ls.K8 * 64;
-    return WStream{(gv4f_ptr)(Ls.wpk) + (size_t)(wave * nfb) * fbs + lane, fbs, nfb == 4 ? 2 : 1};
+    return WStream{(gv4f_ptr)(Ls.wpk) + (size_t)(wave * nfb) * fbs + lane, fbs, nfb == 4 ? 2 : (nfb == 2 ? 1 : 0)};
   };
   const WStream s_in = layer_stream(a.L[0]);
   v4f aq[PC_SLOTS];
@@ -270,8 +285,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel_chain_kernel(const PanelArg
       auto stage_x = [&](int c, float* buf) {
         const int k0 = c * PC_CHUNK;
 #pragma unroll 4
-        for (int j = 0; j < PC_BP / 4; ++j) {
-          int r = wave * (PC_BP / 4) + j;
+        for (int j = 0; j < PC_BP / PC_NW; ++j) {
+          int r = wave * (PC_BP / PC_NW) + j;
           const int rg = r < P ? r : P - 1;
           dma_row(xrows + (size_t)rg * ldx + k0, D - k0, buf + r * (PC_CHUNK + 4));
         }
@@ -279,17 +294,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel_chain_kernel(const PanelArg
       auto stage_cproj = [&](float* buf) {
         const float* cp = a.cproj + (size_t)p0 * a.ldc;
 #pragma unroll 4
-        for (int j = 0; j < PC_BP / 4; ++j) {
-          const int r = wave * (PC_BP / 4) + j;
+        for (int j = 0; j < PC_BP / PC_NW; ++j) {
+          const int r = wave * (PC_BP / PC_NW) + j;
           dma_row(cp + (size_t)r * a.ldc, F, buf + r * (PC_CHUNK + 4));      // the host pads cproj to whole tiles
         }
       };
       stage_x(0, region);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       PC_BARRIER();
-      f32x16 acc[2][2];
-      panel_zero<2>(acc);
-      gv4f_ptr wl = (gv4f_ptr)(L.wpk) + (size_t)(wave * 2) * fbs + lane;
+      constexpr int NFI = PC_NFB_NARROW;
+      f32x16 acc[NFI][2];
+      panel_zero<NFI>(acc);
+      gv4f_ptr wl = (gv4f_ptr)(L.wpk) + (size_t)(wave * NFI) * fbs + lane;
       const WStream s_l1 = layer_stream(a.L[1]);
       for (int c = 0; c < nchunk; ++c) {
         float* const cur = region + (c & 1) * PC_HALF;
@@ -303,8 +319,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel_chain_kernel(const PanelArg
             else if (wave == 1) dma_row(temb_row, F, prm + PC_PS);
           }
         };
-        const WStream wnext = (c + 1 < nchunk) ? WStream{wl + (PC_CHUNK / 8) * 64, fbs, 1} : s_l1;
-        panel_kseg<2>(acc, aq, wl, fbs, n8, cur + l31 * (PC_CHUNK + 4) + 4 * h, PC_CHUNK + 4, wnext, mid);
+        const WStream wnext = (c + 1 < nchunk) ? WStream{wl + (PC_CHUNK / 8) * 64, fbs, NFI == 2 ? 1 : 0} : s_l1;
+        panel_kseg<NFI>(acc, aq, wl, fbs, n8, cur + l31 * (PC_CHUNK + 4) + 4 * h, PC_CHUNK + 4, wnext, mid);
         wl += (PC_CHUNK / 8) * 64;
         PC_WAIT_DMA();
         PC_BARRIER();
@@ -312,10 +328,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel_chain_kernel(const PanelArg
       // h0 = ((acc + b) + temb[t]) + cproj: cproj sits in the buffer the last chunk did not use, h0 goes where the host says
       // (the last chunk's buffer: every wave has left its K loop)
       const unsigned long long tie = STAMP ? __builtin_amdgcn_s_memtime() : 0;
-      const int fl = wave * 64;
+      const int fl = wave * 32 * NFI;
       const PanelIn ci{region + (nchunk & 1) * PC_HALF + l31 * (PC_CHUNK + 4) + fl + 4 * h, PC_CHUNK + 4};
       const PanelOut o{region + L.out_base + l31 * L.out_ld + L.out_col + fl + 4 * h, L.out_ld, nullptr};
-      chain_input<2, 2, PC_PS>(acc, prm, fl, ci, o, lane);
+      chain_input<NFI, 2, PC_PS>(acc, prm, fl, ci, o, lane);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       PC_BARRIER();
       if constexpr (STAMP) c_in_e += __builtin_amdgcn_s_memtime() - tie;
@@ -331,18 +347,19 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel_chain_kernel(const PanelArg
       const float* const pb_ = L.bias; const float* const pg_ = L.gamma; const float* const pbe_ = L.beta;
       auto params = [&]() {
         const int per = F / 256;
-        for (int j = wave; j < 3 * per; j += 4) {
+        for (int j = wave; j < 3 * per; j += PC_NW) {
           const int arr = j / per, piece = j % per;
           const float* src = arr == 0 ? pb_ : (arr == 1 ? pg_ : pbe_);
           dma_row(src + piece * 256, F - piece * 256, prm + arr * PC_PS + piece * 256);
         }
       };
       auto reload = [&](const PanelSeg& sg) {
-        // the spill's lanes are this workgroup's own: wave w wrote features [128 w, 128 w + 128) as 4 x 2 x 4 float4 per lane
-        const float* sp = ws + sg.reload + (size_t)wave * (4 * 2 * 4 * 256) + 4 * lane;
-        float* dst = region + L.in_base + l31 * L.in_ld + sg.col + wave * 128 + 4 * h;
+        // the spill's lanes are this workgroup's own: wave w wrote its 32 NFB features of the 512 as NFB x 2 x 4 float4 per lane
+        constexpr int NFS = PC_NFB_WIDE;
+        const float* sp = ws + sg.reload + (size_t)wave * (NFS * 2 * 4 * 256) + 4 * lane;
+        float* dst = region + L.in_base + l31 * L.in_ld + sg.col + wave * 32 * NFS + 4 * h;
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb) {
+        for (int fb = 0; fb < NFS; ++fb) {
           float4 v[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = ldg4(sp + (size_t)((fb * 8 + j) * 256));
@@ -369,7 +386,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel_chain_kernel(const PanelArg
             if constexpr (STAMP) c_reload += __builtin_amdgcn_s_memtime() - tr0;
           }
           const float* bl = region + L.in_base + l31 * L.in_ld + sg.col + 4 * h;
-          const WStream nxt = (s + 1 < L.nseg) ? WStream{wl + (size_t)sg.n8 * 64, fbs, NFB == 4 ? 2 : 1} : s_next;
+          const WStream nxt = (s + 1 < L.nseg) ? WStream{wl + (size_t)sg.n8 * 64, fbs, NFB == 4 ? 2 : (NFB == 2 ? 1 : 0)} : s_next;
           const unsigned long long tf0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
           if (s == 0) panel_kseg<NFB>(acc, aq, wl, fbs, sg.n8, bl, L.in_ld, nxt, params);
           else panel_kseg<NFB>(acc, aq, wl, fbs, sg.n8, bl, L.in_ld, nxt);
@@ -385,16 +402,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel_chain_kernel(const PanelArg
         const int fl = wave * 32 * NFB;
         float* sp = L.spill >= 0 ? ws + L.spill + (size_t)wave * (NFB * 2 * 4 * 256) + 4 * lane : nullptr;
         const PanelOut o{region + L.out_base + l31 * L.out_ld + L.out_col + fl + 4 * h, L.out_ld, sp};
-        if (L.kind == CK_GN64) chain_gn_silu<64, NFB, 2, PC_PS>(acc, prm, fl, o, lane);
+        // GroupNorm(8, F): groups of 64 channels in the 512-wide layers, 32 in the 256-wide ones (the host checks gw == F / 8)
+        if constexpr (NFB == PC_NFB_WIDE) chain_gn_silu<64, NFB, 2, PC_PS>(acc, prm, fl, o, lane);
         else chain_gn_silu<32, NFB, 2, PC_PS>(acc, prm, fl, o, lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long tf3 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
         PC_BARRIER();
         if constexpr (STAMP) if (l == 8) { fine[4] += tf3 - tk1; fine[5] += __builtin_amdgcn_s_memtime() - tf3; }
-        if constexpr (STAMP) { const unsigned long long tk2 = __builtin_amdgcn_s_memtime(); c_gn_k[NFB / 4] += tk1 - tk0; c_gn_e[NFB / 4] += tk2 - tk1; }
+        if constexpr (STAMP) { const unsigned long long tk2 = __builtin_amdgcn_s_memtime(); c_gn_k[NFB == PC_NFB_WIDE] += tk1 - tk0; c_gn_e[NFB == PC_NFB_WIDE] += tk2 - tk1; }
       };
-      if (F == 512) run(std::integral_constant<int, 4>{});
-      else run(std::integral_constant<int, 2>{});
+      if (F == 512) run(std::integral_constant<int, PC_NFB_WIDE>{});
+      else run(std::integral_constant<int, PC_NFB_NARROW>{});
     }
     const unsigned long long tu2 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -412,13 +430,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel_chain_kernel(const PanelArg
       const float cA = c[0], cB = c[1], cC = c[2];
       WaveXpose<2> xp;
       xp.buf = region + e.xp_base + wave * 2048;
-      float* const prm_w = prm + wave * 128;          // this wave's 128 bias floats of the pass: private, so no barrier between passes
+      constexpr int NFP = PC_NFB_WIDE;
+      float* const prm_w = prm + wave * 32 * NFP;     // this wave's bias floats of the pass: private, so no barrier between passes
       const int npass = (Fpad + 511) / 512;
       for (int ps = 0; ps < npass; ++ps) {
-        const int fw = ps * 512 + wave * 128;
+        const int fw = ps * 512 + wave * 32 * NFP;
         if (fw >= Fpad) break;                // uniform per wave; the workgroup meets again at the barrier behind the loop
         auto bias_dma = [&]() {
-          if (lane < 32) {                    // 32 lanes x 16 B; the DMA honours the exec mask
+          if (lane < 8 * NFP) {               // 8 NFP lanes x 16 B; the DMA honours the exec mask
             int k = 4 * lane;
             const int valid = F - fw > 4 ? F - fw : 4;
             k = k < valid - 4 ? k : valid - 4;
@@ -426,20 +445,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel_chain_kernel(const PanelArg
           }
         };
         const unsigned long long tp0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
-        f32x16 acc[4][2];
-        panel_zero<4>(acc);
+        f32x16 acc[NFP][2];
+        panel_zero<NFP>(acc);
         gv4f_ptr wl = (gv4f_ptr)(L.wpk) + (size_t)(fw / 32) * fbs + lane;
         const float* bl = region + L.in_base + l31 * L.in_ld + L.seg[0].col + 4 * h;
         float* const xw = e.x + (size_t)p0 * e.ldx + fw;
         float4 xpre[8];
         if (F - fw > 0) xp.template issue_rows<true>(xpre, xw, e.ldx, lane, P, F - fw);      // block 0's x_t rows fly under the K loop
-        const WStream nxt = (fw + 512 < Fpad) ? WStream{wl + (size_t)16 * fbs, fbs, 2} : s_in;      // this wave's next pass, or the next unit's input_proj
-        panel_kseg<4>(acc, aq, wl, fbs, K8, bl, L.in_ld, nxt, bias_dma);
+        const WStream nxt = (fw + 512 < Fpad) ? WStream{wl + (size_t)16 * fbs, fbs, NFP == 4 ? 2 : 1} : s_in;      // this wave's next pass, or the next unit's input_proj
+        panel_kseg<NFP>(acc, aq, wl, fbs, K8, bl, L.in_ld, nxt, bias_dma);
         PC_WAIT_DMA();                        // the bias DMA (a whole K loop old)
         const unsigned long long tp1 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
         const float* zrow = e.z ? e.z + (long long)(e.z_t_first - t) * e.z_step_stride + (size_t)p0 * e.ldzz + fw : nullptr;
         float* const mm = e.mut_mask ? e.mut_mask + (size_t)p0 * e.mutation_dim : nullptr;
-        chain_posterior<4, 2, true>(acc, prm_w, 0, xw, e.ldx, P, F - fw, cA, cB, cC, t, zrow, e.ldzz,
+        chain_posterior<NFP, 2, true>(acc, prm_w, 0, xw, e.ldx, P, F - fw, cA, cB, cC, t, zrow, e.ldzz,
                                     e.seed, e.row_offset + (uint32_t)p0, fw, mm, e.mutation_dim, xp, lane, &xpre);
         if constexpr (STAMP) { const unsigned long long tp2 = __builtin_amdgcn_s_memtime(); c_post_k += tp1 - tp0; c_post_e += tp2 - tp1; }
       }
@@ -457,7 +476,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel_chain_kernel(const PanelArg
       c_in += tu1 - tu0; c_gn += tu2 - tu1; c_post += tu3 - tu2;
     }
   }
-  if (STAMP && a.stamps && lane == 0) {
+  if (STAMP && a.stamps && lane == 0 && wave < 4) {
     unsigned long long* o = a.stamps + (size_t)blockIdx.x * 64 + 16 + wave * 8;
     for (int i = 0; i < 6; ++i) o[i] = fine[i];
   }

@@ -151,7 +151,7 @@ static PanelPlan make_plan(const Arch& a, int Dk /* columns of the chain state =
     L.in_base = 0; L.in_ld = cur_ld; L.spill = -1;
     add_w(nl, L.F, L.K8, true);
     p.xp_base = PC_BP * cur_ld;
-    if (p.xp_base + 4 * 2048 > PC_REGION) return p;
+    if (p.xp_base + PC_NW * 2048 > PC_REGION) return p;
     ++nl;
   }
   p.n_layers = nl;
@@ -208,7 +208,7 @@ static int panel_device_limits(int device, int* max_grid) {
     OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_BYTES));
 #endif
     int occ = 0;
-    OSD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, panel_chain_kernel<false>, NTHREADS, PC_LDS_BYTES));
+    OSD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, panel_chain_kernel<false>, PC_THREADS, PC_LDS_BYTES));
     hipDeviceProp_t prop;
     OSD_HIP(hipGetDeviceProperties(&prop, device));
     d.occ = occ < 1 ? occ : 1;
@@ -317,10 +317,10 @@ int panel_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_
     OSD_HIP(hipMemcpyAsync(const_cast<PanelArgs*>(dargs), &host_args[launch], sizeof(PanelArgs), hipMemcpyHostToDevice, s));
     ++launch;
 #ifdef OSD_DIAG
-    if (pa.stamps) hipLaunchKernelGGL(panel_chain_kernel<true>, dim3(grid), dim3(NTHREADS), PC_LDS_BYTES, s, dargs);
+    if (pa.stamps) hipLaunchKernelGGL(panel_chain_kernel<true>, dim3(grid), dim3(PC_THREADS), PC_LDS_BYTES, s, dargs);
     else
 #endif
-    hipLaunchKernelGGL(panel_chain_kernel<false>, dim3(grid), dim3(NTHREADS), PC_LDS_BYTES, s, dargs);
+    hipLaunchKernelGGL(panel_chain_kernel<false>, dim3(grid), dim3(PC_THREADS), PC_LDS_BYTES, s, dargs);
     OSD_HIP(hipGetLastError());
   }
   if (padded) OSD_HIP(launch_copy2d(s, xs, D, x_out, a.D, n, a.D));

@@ -233,9 +233,9 @@ class BiologyAwareDiffusionModel(nn.Module):
         # 256/512-wide architecture, else the per-layer kernels), "chain", "graph" (per-layer kernels; hipGraph iff use_graph)
         self.sampler: str = "auto"
         # which chain kernel: "workspace" (csrc/chain.h: 128-row tiles, activations through a private workspace -- the faster one from
-        # 65 536 rows on), "panel" (csrc/chain_panel.h: 64 patients per workgroup, activations in LDS; bit-identical; fills the chip
-        # from 14 336 rows on; architectures whose panels do not fit run the workspace kernel), None / "auto" (the library's choice:
-        # workspace for large batches, panel for mid-size ones that leave the per-layer kernels' last round of tiles part empty)
+        # 65 536 rows on), "panel" (csrc/chain_panel.h: 64 patients per workgroup, activations in LDS; bit-identical; at its full
+        # rate from 16 384 rows on; architectures whose panels do not fit run the workspace kernel), None / "auto" (the library's choice:
+        # workspace from 65 536 rows on, panel from 10 240 rows on)
         self.chain_variant: Optional[str] = None
         self.last_chain_variant: Optional[str] = None     # the one the most recent chain-kernel sample() used
         self.chain_grid: Optional[int] = None             # workgroup count of the chain kernel (tests)

@@ -30,7 +30,7 @@ if len(sys.argv) > 1:
     m = model(T)
     m.chain_grid = None
     cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(3)).cuda()
-    for variant in ("workspace", "panel", "workspace", "panel"):
+    for variant in ("workspace", "panel") * (int(sys.argv[3]) if len(sys.argv) > 3 else 2):
         m.sampler, m.chain_variant = "chain", variant
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = m.sample(cond, n, seed=5)
