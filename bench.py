@@ -70,6 +70,7 @@ def parse_args():
     ap.add_argument("--train-only", action="store_true", help="run only the training leg (for rocprofv3 --stats)")
     ap.add_argument("--no-reference-workload", action="store_true", help="skip the reference's default generation workload leg")
     ap.add_argument("--reference-workload-only", action="store_true")
+    ap.add_argument("--no-mid-size", action="store_true", help="skip the 32 768-patient comparison (LDS-resident chain kernel vs per-layer kernels) inside the roofline object")
     ap.add_argument("--no-validate", action="store_true", help="skip the config-5 share leg (3 x 125 000 patients + on-device validation)")
     ap.add_argument("--validate-only", action="store_true")
     ap.add_argument("--validate-patients", type=int, default=125_000)
@@ -621,6 +622,25 @@ def roofline_leg(model, args, cond, offset, dev, engine_used, sample_ms, step_fn
     g_s = time.perf_counter() - t0
     model.sampler = keep
     per_layer["patients_per_s_one_step"] = round(args.patients / g_s, 1)
+    # the mid-size batch: 32 768 patients, full T -- below the workspace chain's 512-tile threshold auto runs the LDS-resident chain
+    # kernel (csrc/chain_panel.h; 64 patients per workgroup, activations in LDS), beside the per-layer kernels on the same rows
+    mid = None
+    if not args.no_mid_size and not args.profile_only and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1:
+        mrows = 32768
+        mcond = scenario_conditions(mrows, offset).to(dev)
+        mid = {"rows": mrows, "steps": T}
+        for name, sampler in (("auto", "auto"), ("per_layer", "graph")):
+            model.sampler = sampler
+            model.sample(mcond[:2048], 2048, seed=11)          # engine set-up off the clock
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.sample(mcond, mrows, seed=12)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            tf = mrows * T * FLOP_PER_PATIENT_STEP / dt / 1e12
+            mid[name] = {"patients_per_s": round(mrows / dt, 1), "tflops": round(tf, 2), "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "engine": model.last_sampler + ("/" + model.last_chain_variant if model.last_chain_variant else "")}
+        model.sampler = keep
     return {"bound": "mfma", "kernel": "chain_kernel (persistent: all 12 layers x all T steps of the rank's patients in one launch; "
                                        "v_mfma_f32_32x32x2_f32, 128x128 tiles, LDS-DMA staging)",
             "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -629,7 +649,7 @@ def roofline_leg(model, args, cond, offset, dev, engine_used, sample_ms, step_fn
             "avg_launch_ms": round(launch_ms, 2), "launches_timed": len(sample_ms),
             "algorithmic_flop_per_launch": flop, "patients_per_launch": args.patients, "steps_per_launch": T,
             "algorithmic_hbm_bytes_per_launch": float(args.patients) * T * 16000,
-            "per_layer_engine": per_layer}
+            "per_layer_engine": per_layer, "mid_size_batch": mid}
 
 
 if __name__ == "__main__":

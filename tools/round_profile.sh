@@ -4,8 +4,8 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_final
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench100k -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-train --no-validate --no-reference-workload > $out/bench100k.log 2>&1; echo "bench100k (chain engine) rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench100k_graph -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-train --no-validate --no-reference-workload --sampler graph > $out/bench100k_graph.log 2>&1; echo "bench100k_graph rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench100k -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-train --no-validate --no-reference-workload --no-mid-size > $out/bench100k.log 2>&1; echo "bench100k (chain engine) rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench100k_graph -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-train --no-validate --no-reference-workload --no-mid-size --sampler graph > $out/bench100k_graph.log 2>&1; echo "bench100k_graph rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/train -- python3 bench.py --train-only --train-steps 40 > $out/train.log 2>&1; echo "train rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/validate -- python3 bench.py --validate-only > $out/validate.log 2>&1; echo "validate rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/refw -- python3 bench.py --reference-workload-only > $out/refw.log 2>&1; echo "refw rc=$?"
