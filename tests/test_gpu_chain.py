@@ -79,6 +79,22 @@ def test_auto_takes_the_lds_resident_chain_for_mid_size_batches():
     assert m.last_sampler == "graph"
 
 
+@pytest.mark.parametrize("hidden,dims,n", [
+    ([256, 256], dict(mutation_dim=30, expression_dim=560, pathway_dim=10, condition_dim=3), 150),               # one skip, kept in the panel
+    ([256, 512, 512, 256], dict(mutation_dim=40, expression_dim=700, pathway_dim=28, condition_dim=5), 97),       # two spilled skips + one kept
+    ([256, 512, 256], dict(mutation_dim=50, expression_dim=966, pathway_dim=8, condition_dim=3), 64),             # D = 1024: whole chunks, whole passes
+])
+def test_panel_chain_other_architectures_bitwise(hidden, dims, n):
+    """The LDS-resident chain's panel planner (csrc/chain_panel.hip: make_plan) on other layer lists: which skip stays in panel
+    columns [256, 512), which ones are spilled in fragment order and reloaded between K segments, chunk / pass counts."""
+    m = _model(5, hidden=hidden, seed=12, **dims)
+    cond = torch.randn(n, dims["condition_dim"], generator=torch.Generator().manual_seed(2)).cuda()
+    ref, ref_mask = _run(m, cond, n, "graph", seed=3)
+    m.chain_grid = 2
+    out, mask = _run(m, cond, n, "chain", "panel", seed=3)
+    assert torch.equal(out, ref) and torch.equal(mask, ref_mask)
+
+
 def test_panel_chain_vs_oracle_injected_draws_and_unaligned_dims():
     """The LDS-resident chain kernel against the CPU oracle (injected x_T / z: 200 rows = three 64-patient units + 8 rows, T = 20),
     then at the reference's real dims 62/5054/26 (D = 5142, D % 4 = 2: padded state, eleven output passes) against the per-layer
