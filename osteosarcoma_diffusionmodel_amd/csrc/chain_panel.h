@@ -123,9 +123,15 @@ __device__ __forceinline__ void ws_prime(v4f (&aq)[PC_SLOTS], const WStream& s) 
 // the youngest outstanding memory operations: s_waitcnt vmcnt(16) then means "the DMA pieces have landed".
 // MFMA order = the tile kernels' order: 8-k blocks ascending, inside a block the pairs (e, e + 4).
 struct NoMid { __device__ __forceinline__ void operator()() const {} };
-template <int NFB, class Mid = NoMid>
+// FRESH: the accumulators start at zero -- the segment's first MFMA of each takes the constant 0 as its C operand instead of a
+// register block that 64-128 v_accvgpr_write would have to clear first (same bits: 0 + a b either way).
+template <int NFB, bool FRESH = false, class Mid = NoMid>
 __device__ __forceinline__ void panel_kseg(f32x16 (&acc)[NFB][2], v4f (&aq)[PC_SLOTS], gv4f_ptr wl, int fbs, int n8, const float* bl, int ldb,
                                            const WStream& nxt, const Mid& mid = Mid()) {
+  // (Tried, with eight waves: the two waves of a SIMD taking turns at the higher issue priority -- left alone the arbiter favours
+  // the older one, which reaches the layer's barrier early while its partner finishes on its own at a lone wave's rate: 5 600 of a
+  // chunk's 38 000 cycles, 21 000 of a 512 x 512 layer's 141 000.  s_setprio swapped every 8-k block: 0.740 -> 0.703 of peak; swapped
+  // once in the middle of a segment: 0.730.  Streaming one wave's MFMAs is what the SIMD does best; removed.)
   constexpr int DEPTH = PC_SLOTS / NFB;
   static_assert(DEPTH % 2 == 0, "the B fragments alternate between two register sets");
   v4f bq[2][2];
@@ -143,7 +149,14 @@ __device__ __forceinline__ void panel_kseg(f32x16 (&acc)[NFB][2], v4f (&aq)[PC_S
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-          for (int pb = 0; pb < 2; ++pb) acc[fb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[d * NFB + fb][e], bq[d & 1][pb][e], acc[fb][pb], 0, 0, 0);
+          for (int pb = 0; pb < 2; ++pb) {
+            if (FRESH && first && d == 0 && e == 0) {
+              const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              acc[fb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[d * NFB + fb][e], bq[d & 1][pb][e], zero, 0, 0, 0);
+            } else {
+              acc[fb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[d * NFB + fb][e], bq[d & 1][pb][e], acc[fb][pb], 0, 0, 0);
+            }
+          }
       if (first && d == 0) mid();
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb) {
@@ -217,6 +230,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void panel_chain_kernel(const PanelA
   float* const ws = a.ws + (long long)blockIdx.x * a.ws_stride;
 
   unsigned long long c_dep = 0, c_in = 0, c_gn = 0, c_post = 0, c_units = 0;
+  unsigned long long fin[3] = {0, 0, 0};                 // STAMP: this wave's chunk 3 of input_proj: K loop, DMA wait, barrier
   unsigned long long fine[6] = {0, 0, 0, 0, 0, 0};      // STAMP: this wave's phases of layer 8 (512 -> 512): zero+setup, K loop, DMA wait, barrier, epilogue, barrier
   unsigned long long c_in_e = 0, c_gn_k[2] = {0, 0}, c_gn_e[2] = {0, 0}, c_post_k = 0, c_post_e = 0, c_reload = 0;      // STAMP: K loops / epilogues by layer class
   const unsigned long long c_start = STAMP ? __builtin_amdgcn_s_memtime() : 0;
@@ -320,10 +334,14 @@ __global__ __launch_bounds__(PC_THREADS, 1) void panel_chain_kernel(const PanelA
           }
         };
         const WStream wnext = (c + 1 < nchunk) ? WStream{wl + (PC_CHUNK / 8) * 64, fbs, NFI == 2 ? 1 : 0} : s_l1;
-        panel_kseg<NFI>(acc, aq, wl, fbs, n8, cur + l31 * (PC_CHUNK + 4) + 4 * h, PC_CHUNK + 4, wnext, mid);
+        const unsigned long long ti0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+        panel_kseg<NFI, false>(acc, aq, wl, fbs, n8, cur + l31 * (PC_CHUNK + 4) + 4 * h, PC_CHUNK + 4, wnext, mid);
         wl += (PC_CHUNK / 8) * 64;
+        const unsigned long long ti1 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
         PC_WAIT_DMA();
+        const unsigned long long ti2 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
         PC_BARRIER();
+        if constexpr (STAMP) if (c == 3) { fin[0] += ti1 - ti0; fin[1] += ti2 - ti1; fin[2] += __builtin_amdgcn_s_memtime() - ti2; }
       }
       // h0 = ((acc + b) + temb[t]) + cproj: cproj sits in the buffer the last chunk did not use, h0 goes where the host says
       // (the last chunk's buffer: every wave has left its K loop)
@@ -372,7 +390,6 @@ __global__ __launch_bounds__(PC_THREADS, 1) void panel_chain_kernel(const PanelA
         const unsigned long long tk0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
         const int fbs = L.K8 * 64;
         f32x16 acc[NFB][2];
-        panel_zero<NFB>(acc);
         gv4f_ptr wl = (gv4f_ptr)(L.wpk) + (size_t)(wave * NFB) * fbs + lane;
         const WStream s_next = layer_stream(a.L[l + 1]);
         for (int s = 0; s < L.nseg; ++s) {
@@ -388,7 +405,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void panel_chain_kernel(const PanelA
           const float* bl = region + L.in_base + l31 * L.in_ld + sg.col + 4 * h;
           const WStream nxt = (s + 1 < L.nseg) ? WStream{wl + (size_t)sg.n8 * 64, fbs, NFB == 4 ? 2 : (NFB == 2 ? 1 : 0)} : s_next;
           const unsigned long long tf0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
-          if (s == 0) panel_kseg<NFB>(acc, aq, wl, fbs, sg.n8, bl, L.in_ld, nxt, params);
+          if (s == 0) panel_kseg<NFB, true>(acc, aq, wl, fbs, sg.n8, bl, L.in_ld, nxt, params);
           else panel_kseg<NFB>(acc, aq, wl, fbs, sg.n8, bl, L.in_ld, nxt);
           wl += (size_t)sg.n8 * 64;
           if constexpr (STAMP) if (l == 8) { asm volatile("s_nop 0" ::: "memory"); fine[0] += tf0 - tk0; fine[1] += __builtin_amdgcn_s_memtime() - tf0; }
@@ -446,14 +463,13 @@ __global__ __launch_bounds__(PC_THREADS, 1) void panel_chain_kernel(const PanelA
         };
         const unsigned long long tp0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
         f32x16 acc[NFP][2];
-        panel_zero<NFP>(acc);
         gv4f_ptr wl = (gv4f_ptr)(L.wpk) + (size_t)(fw / 32) * fbs + lane;
         const float* bl = region + L.in_base + l31 * L.in_ld + L.seg[0].col + 4 * h;
         float* const xw = e.x + (size_t)p0 * e.ldx + fw;
         float4 xpre[8];
         if (F - fw > 0) xp.template issue_rows<true>(xpre, xw, e.ldx, lane, P, F - fw);      // block 0's x_t rows fly under the K loop
         const WStream nxt = (fw + 512 < Fpad) ? WStream{wl + (size_t)16 * fbs, fbs, NFP == 4 ? 2 : 1} : s_in;      // this wave's next pass, or the next unit's input_proj
-        panel_kseg<NFP>(acc, aq, wl, fbs, K8, bl, L.in_ld, nxt, bias_dma);
+        panel_kseg<NFP, true>(acc, aq, wl, fbs, K8, bl, L.in_ld, nxt, bias_dma);
         PC_WAIT_DMA();                        // the bias DMA (a whole K loop old)
         const unsigned long long tp1 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
         const float* zrow = e.z ? e.z + (long long)(e.z_t_first - t) * e.z_step_stride + (size_t)p0 * e.ldzz + fw : nullptr;
@@ -479,6 +495,8 @@ __global__ __launch_bounds__(PC_THREADS, 1) void panel_chain_kernel(const PanelA
   if (STAMP && a.stamps && lane == 0 && wave < 4) {
     unsigned long long* o = a.stamps + (size_t)blockIdx.x * 64 + 16 + wave * 8;
     for (int i = 0; i < 6; ++i) o[i] = fine[i];
+    o[6] = fin[0]; o[7] = fin[1];
+    a.stamps[(size_t)blockIdx.x * 64 + 48 + wave] = fin[2];
   }
   if (STAMP && a.stamps && tid == 0) {
     unsigned long long* o = a.stamps + (size_t)blockIdx.x * 64;

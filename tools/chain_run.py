@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run the reverse chain once at a chosen T (diagnostic target of rocprofv3 passes): chain_run.py <rows> <T> <sampler>."""
+"""Run the reverse chain once at a chosen T (diagnostic target of rocprofv3 passes): chain_run.py <rows> <T> <sampler> [workspace|panel]."""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -12,8 +12,9 @@ conf = {"model": dict(CONF["model"])}; conf["model"]["diffusion"] = {"num_steps"
 torch.manual_seed(0)
 m = BiologyAwareDiffusionModel(50, 1900, 50, 3, conf).cuda().eval()
 m.sampler = sys.argv[3] if len(sys.argv) > 3 else "chain"
+m.chain_variant = sys.argv[4] if len(sys.argv) > 4 else "workspace"
 cond = scenario_conditions(n, 0).cuda()
 for i in range(2):
     out = m.sample(cond, n, seed=1 + i)
 torch.cuda.synchronize()
-print("ok", m.last_sampler, float(out.abs().max()))
+print("ok", m.last_sampler, m.last_chain_variant, float(out.abs().max()))

@@ -36,4 +36,8 @@ print("  layer 8 (512 -> 512, ideal 131072 MFMA cycles), per wave: setup | K loo
 for w in range(4):
     c = s[:, 16 + 8 * w: 22 + 8 * w].sum(axis=0) / units.sum()
     print(f"    wave {w}: " + "".join(f"{v:10.0f}" for v in c))
+print("  input_proj chunk 3 (256 k; ideal 32768 MFMA cycles per SIMD), per wave: K loop | DMA wait | barrier")
+for w in range(4):
+    c = [s[:, 16 + 8 * w + 6].sum() / units.sum(), s[:, 16 + 8 * w + 7].sum() / units.sum(), s[:, 48 + w].sum() / units.sum()]
+    print(f"    wave {w}: " + "".join(f"{v:10.0f}" for v in c))
 mf = {"input": 64*2*2048*256/256, "gn256": 64*2*(512*256+256*256*4+1024*256)/256 if False else 0}

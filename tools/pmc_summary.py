@@ -8,6 +8,7 @@ dur = collections.defaultdict(list)
 
 
 def klass(name):
+    if "panel_chain_kernel" in name: return "panel_chain_kernel"
     if "chain_kernel" in name: return "chain_kernel"
     if "wgrad_group_kernel" in name: return "wgrad_group_kernel"
     if "gemm_glds_kernel" not in name or "128, 128, 64, 64" not in name: return None
@@ -45,7 +46,7 @@ for k in sorted(vals):
     n = len(vals[k].get("GRBM_GUI_ACTIVE", []))
     print(f"| {k} | {n} | {sum(dur[k]) / max(len(dur[k]), 1) / 1e6:.3f} | {busy:.3f} | {avg(k, 'SQ_LDS_BANK_CONFLICT'):.0f} | {fetch:.0f} | {write:.0f} | "
           f"{tr / 1e6:.1f} | {hit / (hit + miss):.3f} | {avg(k, 'SQ_INSTS_VALU'):.0f} |")
-units = {k: (chain_units if k == "chain_kernel" else 32768.0) for k in traffic}
+units = {k: (chain_units if k in ("chain_kernel", "panel_chain_kernel") else 32768.0) for k in traffic}
 print()
 print("traffic_json:", json.dumps({"rows_per_launch": 32768, "units_per_launch": units, "traffic_bytes_per_launch": traffic,
                                    "unit_of": {"chain_kernel": "patient-steps", "default": "rows"}, "source": f"profiles/{tag}_pmc.md"}))
