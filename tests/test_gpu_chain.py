@@ -1,4 +1,5 @@
-"""GPU: the persistent reverse-chain kernel (csrc/chain.h) -- every layer and every step of sample() in one launch, row
+"""GPU: the persistent reverse-chain kernels (csrc/chain.h: 128-row tiles through a workspace; csrc/chain_panel.h: 64 patients
+resident in LDS) -- every layer and every step of sample() in one launch, row
 tiles handed between workgroups through agent-scope release / acquire -- against the per-layer kernels (bitwise: same
 tile loop, same epilogues, same Philox addressing) and against the CPU oracle (models/diffusion.py:382-449).
 
