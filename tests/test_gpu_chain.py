@@ -213,6 +213,9 @@ def test_config3_full_size_engines_agree():
     assert torch.equal(out_c, out_g), f"max|d| = {(out_c - out_g).abs().max().item():.3e} of {out_g.abs().max().item():.3e}"
     assert torch.equal(mask_c, mask_g)
     assert set(mask_c.unique().tolist()) <= {0.0, 1.0}
+    # ... and on the LDS-resident chain kernel (1 563 units of 64 patients over 256 workgroups, 1.5 x 10^6 hand-offs)
+    out_p, mask_p = _run(m, cond, n, "chain", "panel", seed=2024, row_offset=0)
+    assert torch.equal(out_p, out_g) and torch.equal(mask_p, mask_g)
 
 
 
