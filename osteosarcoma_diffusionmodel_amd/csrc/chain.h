@@ -226,13 +226,14 @@ __device__ __forceinline__ void chain_input(f32x16 (&acc)[NFB][NPB], const float
 #endif
 // PRE (chain_panel.h): the caller has already requested block 0's x_t rows into *pre (WaveXpose::issue_rows, same guards); every
 // block then requests the next one's rows before it computes, so no block waits for a global round trip.  Data movement only.
-template <int NFB, int NPB, bool PRE = false>
+template <int NFB, int NPB, bool PRE = false, bool GUARD = true>
 __device__ __forceinline__ void chain_posterior(f32x16 (&acc)[NFB][NPB], const float* __restrict__ prm, int fl, float* __restrict__ x, int ldx,
                                                 int prow, int pcol, float cA, float cB, float cC, int t, const float* __restrict__ zrow, int ldzz,
                                                 uint64_t seed, uint32_t row_id0, int f_glob, float* __restrict__ mut_mask, int mutation_dim,
                                                 const WaveXpose<NPB>& xp, int lane, float4 (*pre)[4 * NPB] = nullptr) {
   const int l31 = lane & 31, h = lane >> 5;
-  constexpr bool GUARD = true;                // a guard-free variant for full blocks was measured: +0.3 % (noise), 4 spills, +14 KB of code
+  // GUARD = false: every row and every feature of the wave's block exists (chain.h measured a guard-free variant of its own epilogue:
+  // +0.3 % for 4 spills and 14 KB of code, so it always guards; chain_panel.h picks per pass)
   if (prow <= 0) return;                      // uniform over the wave
   const bool do_mask = t == 0 && mut_mask != nullptr;      // uniform
 #pragma unroll

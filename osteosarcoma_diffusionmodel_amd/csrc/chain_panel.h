@@ -32,6 +32,11 @@
 
 namespace osd {
 
+// 1: full output blocks take a guard-free instantiation of the posterior epilogue.  Measured 0.740 -> 0.709 of peak: the kernel is
+// 51.6 KB of code (chain.h: 38 KB) and the second instantiation pushes it past the 64 KB instruction cache two CUs share.
+#ifndef PC_POST_NOGUARD
+#define PC_POST_NOGUARD 0
+#endif
 constexpr int PC_BP = 64;                         // patients per unit
 #ifndef PC_NW
 #define PC_NW 8
@@ -474,8 +479,12 @@ __global__ __launch_bounds__(PC_THREADS, 1) void panel_chain_kernel(const PanelA
         const unsigned long long tp1 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
         const float* zrow = e.z ? e.z + (long long)(e.z_t_first - t) * e.z_step_stride + (size_t)p0 * e.ldzz + fw : nullptr;
         float* const mm = e.mut_mask ? e.mut_mask + (size_t)p0 * e.mutation_dim : nullptr;
-        chain_posterior<NFP, 2, true>(acc, prm_w, 0, xw, e.ldx, P, F - fw, cA, cB, cC, t, zrow, e.ldzz,
-                                    e.seed, e.row_offset + (uint32_t)p0, fw, mm, e.mutation_dim, xp, lane, &xpre);
+        if (PC_POST_NOGUARD && P == PC_BP && F - fw >= 32 * NFP)      // a full block: no clamps, no per-element bounds
+          chain_posterior<NFP, 2, true, false>(acc, prm_w, 0, xw, e.ldx, P, F - fw, cA, cB, cC, t, zrow, e.ldzz,
+                                               e.seed, e.row_offset + (uint32_t)p0, fw, mm, e.mutation_dim, xp, lane, &xpre);
+        else
+          chain_posterior<NFP, 2, true>(acc, prm_w, 0, xw, e.ldx, P, F - fw, cA, cB, cC, t, zrow, e.ldzz,
+                                        e.seed, e.row_offset + (uint32_t)p0, fw, mm, e.mutation_dim, xp, lane, &xpre);
         if constexpr (STAMP) { const unsigned long long tp2 = __builtin_amdgcn_s_memtime(); c_post_k += tp1 - tp0; c_post_e += tp2 - tp1; }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
