@@ -271,6 +271,7 @@ struct EpiGnSilu {
 // g_add: a partial gradient already in the gy buffer (the skip connection's share) is added first, in place.
 template <int GW, bool DROP>
 struct EpiGnBwd {
+  static constexpr bool KSPLIT2 = true;            // launch.h: the two-wave-group variant of gemm_kernel is instantiated for the 64 x 64 tile
   static constexpr bool COUNTED_STORES = false;
   static constexpr bool XBUF = false;
   template <class A> static __device__ __forceinline__ void slice(A&, int) {}

@@ -211,14 +211,19 @@ struct StageNK {
 // gemm_tile computes the BF x BP tile at (f0, p0) with all 256 threads of the workgroup; `smem` = T::LDS_BYTES of LDS.  Called by
 // gemm_kernel (one tile per workgroup) and by the persistent backward kernel (bwd_persist.h: a workgroup runs many tiles of
 // different GEMMs, with a barrier between two uses of `smem`).
-template <class T, bool AKC, bool BKC, class Epi, bool FAST>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi::Args& ea, int f0, int p0, float* smem) {
+// NG = 2 (gemm_kernel<..., 2>: 512 threads): two wave groups, each with its own staging buffers, reduce one half of the K tiles each;
+// group 1 hands its accumulators to group 0 through LDS and leaves, group 0 adds them and runs the epilogue (the two-wave-group
+// idea of gemm_glds.h for the register-staged kernel: the first dgrad of a training step is 256 tiles x 63 K tiles).
+template <class T, bool AKC, bool BKC, class Epi, bool FAST, int NG = 1>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi::Args& ea, int f0, int p0, float* smem_all) {
+  const int grp = NG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  float* const smem = smem_all + grp * (T::LDS_BYTES / 4);
   float* As0 = smem;
   float* As1 = smem + T::A_ELEMS;
   float* Bs0 = smem + 2 * T::A_ELEMS;
   float* Bs1 = smem + 2 * T::A_ELEMS + T::B_ELEMS;
 
-  const int tid = threadIdx.x;
+  const int tid = NG == 1 ? threadIdx.x : (threadIdx.x & (NTHREADS - 1));      // position inside the wave group
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wf = (wave / T::NWP) * T::WF;   // wave's feature offset inside the block tile
@@ -285,23 +290,53 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
   //   shadow of the matrix pipe; one barrier per iteration publishes tile kt+1.
   // (writing buffer (kt+1)&1 during iteration kt is safe: its tile kt-1 was last read in
   //  iteration kt-1, which every wave left through the barrier.)
-  const int nk = (g.K + BK - 1) / BK;
-  gload(0);
-  lstore(As0, Bs0, 0);
-  if (nk > 1) gload(BK);
+  const int nk_all = (g.K + BK - 1) / BK;
+  // NG = 2: group 0 reduces K tiles [0, nk), group 1 [kb, kb + kc); both walk nk iterations (the barrier counts every wave)
+  const int nk = NG == 1 ? nk_all : (nk_all + 1) / 2;
+  const int kb = grp ? nk : 0;
+  const int kc = NG == 1 ? nk : (grp ? nk_all - nk : nk);
+  if (kc > 0) {
+    gload(kb * BK);
+    lstore(As0, Bs0, kb * BK);
+    if (kc > 1) gload((kb + 1) * BK);
+  }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     float* Ac = (kt & 1) ? As1 : As0;
     float* Bc = (kt & 1) ? Bs1 : Bs0;
     float* An = (kt & 1) ? As0 : As1;
     float* Bn = (kt & 1) ? Bs0 : Bs1;
-    compute(Ac, Bc, 0);
-    if (kt + 1 < nk) lstore(An, Bn, (kt + 1) * BK);
-    compute(Ac, Bc, 1);
-    if (kt + 2 < nk) gload((kt + 2) * BK);
-    compute(Ac, Bc, 2);
-    compute(Ac, Bc, 3);
+    if (NG == 1 || kt < kc) {             // uniform per wave group (group 1 may have one tile less)
+      compute(Ac, Bc, 0);
+      if (kt + 1 < kc) lstore(An, Bn, (kb + kt + 1) * BK);
+      compute(Ac, Bc, 1);
+      if (kt + 2 < kc) gload((kb + kt + 2) * BK);
+      compute(Ac, Bc, 2);
+      compute(Ac, Bc, 3);
+    }
     __syncthreads();
+  }
+  if constexpr (NG == 2) {
+    // group 1's accumulators through its own staging buffers (free since the K loop's last barrier): [wave][register][lane]
+    constexpr int NREG = T::NFB * T::NPB * 16;
+    static_assert(4 * NREG * 64 * 4 <= T::LDS_BYTES, "accumulator hand-over must fit the group's staging buffers");
+    float* const red = smem_all + T::LDS_BYTES / 4 + wave * (NREG * 64);
+    if (grp == 1) {
+#pragma unroll
+      for (int i = 0; i < T::NFB; ++i)
+#pragma unroll
+        for (int j = 0; j < T::NPB; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((i * T::NPB + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;                  // uniform per wave; finished waves no longer count at the workgroup barrier
+#pragma unroll
+    for (int i = 0; i < T::NFB; ++i)
+#pragma unroll
+      for (int j = 0; j < T::NPB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * T::NPB + j) * 16 + r) * 64 + lane];
   }
 
   const auto pre = Epi::template prefetch<T::NFB, FAST>(ea, f0 + wf, lane, g.F);
@@ -315,8 +350,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
 }
 
 // ---- the kernel -----------------------------------------------------------------
-template <class T, bool AKC, bool BKC, class Epi, bool FAST>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g, typename Epi::Args ea) {
+template <class T, bool AKC, bool BKC, class Epi, bool FAST, int NG = 1>
+__global__ __launch_bounds__(NTHREADS * NG, NG == 1 ? 2 : 1) void gemm_kernel(GemmArgs g, typename Epi::Args ea) {
   // split-K (wgrad: the reduction runs over the batch): slice y owns k in [y*kchunk, (y+1)*kchunk) and
   // writes its partial tile to its own slab (Epi::slice moves the output pointer); single K panel only.
   if (g.kchunk > 0) {
@@ -337,7 +372,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g, typename 
   const int ft = idx % nft;
   const int pt = (idx / nft) * 8 + (b & 7);
   if (pt >= npt) return;
-  gemm_tile<T, AKC, BKC, Epi, FAST>(g, ea, ft * T::BF, pt * T::BP, smem);
+  gemm_tile<T, AKC, BKC, Epi, FAST, NG>(g, ea, ft * T::BF, pt * T::BP, smem);
 }
 
 // element (fb, reg) of a lane's fragment is feature  f_wave + 32*fb + 8*(reg>>2) + 4*h + (reg&3)

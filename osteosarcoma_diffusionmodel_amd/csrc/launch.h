@@ -34,13 +34,17 @@ struct KernelReg { const void* fn; int lds_bytes; };
 std::vector<KernelReg>& kernel_registry();
 hipError_t prepare_kernels();
 
-template <class T, bool AKC, bool BKC, class Epi, bool FAST>
+template <class T, bool AKC, bool BKC, class Epi, bool FAST, int NG = 1>
 struct GemmRegistrar {
-  GemmRegistrar() { kernel_registry().push_back({reinterpret_cast<const void*>(gemm_kernel<T, AKC, BKC, Epi, FAST>), T::LDS_BYTES}); }
+  GemmRegistrar() { kernel_registry().push_back({reinterpret_cast<const void*>(gemm_kernel<T, AKC, BKC, Epi, FAST, NG>), NG * T::LDS_BYTES}); }
   static GemmRegistrar instance;
 };
-template <class T, bool AKC, bool BKC, class Epi, bool FAST>
-GemmRegistrar<T, AKC, BKC, Epi, FAST> GemmRegistrar<T, AKC, BKC, Epi, FAST>::instance;
+template <class T, bool AKC, bool BKC, class Epi, bool FAST, int NG>
+GemmRegistrar<T, AKC, BKC, Epi, FAST, NG> GemmRegistrar<T, AKC, BKC, Epi, FAST, NG>::instance;
+
+// which (tile, epilogue) pairs get the two-wave-group instantiations: the epilogue opts in (static constexpr bool KSPLIT2)
+template <class E, class = void> struct epi_ksplit2 : std::false_type {};
+template <class E> struct epi_ksplit2<E, std::void_t<decltype(E::KSPLIT2)>> : std::integral_constant<bool, E::KSPLIT2> {};
 
 inline bool ptr_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -64,6 +68,14 @@ hipError_t launch_gemm_v(hipStream_t s, const GemmArgs& g, const typename Epi::A
   auto kern = gemm_kernel<T, AKC, BKC, Epi, FAST>;
   const int grid = gemm_grid(g.F, g.P, T::BF, T::BP);
   const int slices = g.kchunk > 0 ? (g.K + g.kchunk - 1) / g.kchunk : 1;
+  if constexpr (epi_ksplit2<Epi>::value && T::BF * T::BP <= 64 * 64 && FAST) {
+    // two wave groups (gemm.h): about one tile per CU and a long K loop -- the first dgrad of a training step (K = D = 2000: 63 K tiles)
+    if (g.ksplit && slices == 1 && grid <= 320 && g.K >= 32 * BK) {
+      (void)&GemmRegistrar<T, AKC, BKC, Epi, FAST, 2>::instance;
+      hipLaunchKernelGGL((gemm_kernel<T, AKC, BKC, Epi, FAST, 2>), dim3(grid), dim3(2 * NTHREADS), 2 * T::LDS_BYTES, s, g, ea);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL(kern, dim3(grid, slices), dim3(NTHREADS), T::LDS_BYTES, s, g, ea);
   return hipGetLastError();
 }
@@ -85,10 +97,6 @@ struct GldsRegistrar {
 };
 template <class T, class Epi, int NG>
 GldsRegistrar<T, Epi, NG> GldsRegistrar<T, Epi, NG>::instance;
-
-// which (tile, epilogue) pairs get the two-wave-group instantiation: the epilogue opts in (static constexpr bool KSPLIT2)
-template <class E, class = void> struct epi_ksplit2 : std::false_type {};
-template <class E> struct epi_ksplit2<E, std::void_t<decltype(E::KSPLIT2)>> : std::integral_constant<bool, E::KSPLIT2> {};
 
 int persist_mode();   // OSD_PERSIST env: 0 (default) one tile per workgroup; 1 / 2: persistent tile walk on 512 / 256 workgroups
 

@@ -325,6 +325,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
                          bool* skip_done = nullptr) -> int {
     GemmArgs g{};
     g.A = w; g.lda = ldw; g.B0 = gz_next; g.ldb0 = ldg; g.K0 = nout; g.F = kin; g.P = (int)n; g.K = nout;
+    g.ksplit = h->train_ksplit != 0;       // launch.h: two wave groups where a launch has ~one tile per CU and >= 32 K tiles (the first dgrad)
     GnBwdEpi e{};
     e.z = z; e.ldz = kin; e.stats = stats; e.gamma = h->params[ln.gamma]; e.beta = h->params[ln.beta];
     e.gz = gz_out; e.ldg = kin; e.gy = gy_buf; e.ldy = kin; e.accumulate = accumulate ? 1 : 0;
