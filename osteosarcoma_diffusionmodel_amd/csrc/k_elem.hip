@@ -121,7 +121,8 @@ hipError_t launch_q_sample(hipStream_t s, const float* x0, const int* t, const f
 // condition row into cond_out.  Replaces gather + k_mixup3 + k_q_sample (three passes over the batch) by one.
 // One workgroup = QS_ROWS batch rows; a thread walks the row's 16-byte quads t, t + 256, ... (no 64-bit division per element, the
 // row's scalars -- t, the two schedule values, the two dataset rows -- are wave-uniform and loaded once), QS_ROWS x 2 independent
-// quads per thread in flight at D = 2000.  First version (one quad per thread over a flat index): 37 us = 3.6 TB/s.
+// quads per thread in flight at D = 2000.  First version (one quad per thread over a flat index): 37 us = 3.6 TB/s; row by row with
+// the zero list folded in: 40 us; all QS_ROWS rows' loads ahead of the stores: 35.4 us = 3.8 TB/s (QS_ROWS 2: 35.9, 8: 46.8).
 constexpr int QS_ROWS = 4;
 __global__ __launch_bounds__(256) void k_q_sample_src(BatchSrc b, const int* t, const float* sqrt_ac, const float* sqrt_1m, const float* noise_in,
                                                       int64_t rows, int cols, int cd, uint64_t seed, uint32_t row_offset, float* x_t, int ldxt,
@@ -129,10 +130,18 @@ __global__ __launch_bounds__(256) void k_q_sample_src(BatchSrc b, const int* t, 
   zero_list(zl);
   const int c4n = (cols + 3) >> 2;
   for (int64_t r0 = (int64_t)blockIdx.x * QS_ROWS; r0 < rows; r0 += (int64_t)gridDim.x * QS_ROWS) {
+    // the rows' scalars first (wave-uniform loads), then per 256-quad column block ALL dataset loads of the QS_ROWS rows before any
+    // store: the stores may alias the loads as far as hipcc knows, so a load placed behind a store waits for it -- one row at a time
+    // the kernel ran at 3.4 TB/s with two loads in flight per thread
+    float a[QS_ROWS], bb[QS_ROWS];
+    const float* xa[QS_ROWS]; const float* xb[QS_ROWS];
+    int nrow = 0;
 #pragma unroll
     for (int rr = 0; rr < QS_ROWS; ++rr) {
       const int64_t r = r0 + rr;
-      if (r >= rows) break;                          // uniform over the workgroup
+      a[rr] = bb[rr] = 0.f; xa[rr] = xb[rr] = b.data;
+      if (r >= rows) continue;                       // uniform over the workgroup
+      nrow = rr + 1;
       int tt;
       if (t) tt = t[r];
       else {
@@ -140,38 +149,52 @@ __global__ __launch_bounds__(256) void k_q_sample_src(BatchSrc b, const int* t, 
         tt = (int)(((uint64_t)rnd.x * (uint64_t)T) >> 32);
         if (threadIdx.x == 0) t_out[r] = tt;
       }
-      const float a = sqrt_ac[tt], bb = sqrt_1m[tt];
+      a[rr] = sqrt_ac[tt]; bb[rr] = sqrt_1m[tt];
       const int64_t ia = b.idx_a ? b.idx_a[r] : r;
       const int64_t ib = b.idx_b ? b.idx_b[r] : 0;
-      const float* xa = b.data + ia * b.ldd;
-      const float* xb = b.data + ib * b.ldd;
+      xa[rr] = b.data + ia * b.ldd;
+      xb[rr] = b.data + ib * b.ldd;
       if ((int)threadIdx.x < cd && cond_out) {
         float v = b.cond[ia * b.ldc + threadIdx.x];
         if (b.idx_b) v = __fadd_rn(__fmul_rn(b.lam, v), __fmul_rn(b.oml, b.cond[ib * b.ldc + threadIdx.x]));
         cond_out[r * cd + threadIdx.x] = v;
       }
-      for (int q = threadIdx.x; q < c4n; q += 256) {
-        const int c = 4 * q;
-        float4 x = ld4g(xa, c, cols);
+    }
+    for (int q0 = 0; q0 < c4n; q0 += 256) {
+      const int q = q0 + (int)threadIdx.x;
+      if (q >= c4n) continue;
+      const int c = 4 * q;
+      float4 x[QS_ROWS], y[QS_ROWS], nz[QS_ROWS];
+#pragma unroll
+      for (int rr = 0; rr < QS_ROWS; ++rr) {
+        if (rr >= nrow) break;
+        x[rr] = ld4g(xa[rr], c, cols);
+        if (b.idx_b) y[rr] = ld4g(xb[rr], c, cols);
+        if (noise_in) nz[rr] = ld4g(noise_in + (r0 + rr) * cols, c, cols);
+      }
+#pragma unroll
+      for (int rr = 0; rr < QS_ROWS; ++rr) {
+        if (rr >= nrow) break;
+        const int64_t r = r0 + rr;
+        float4 xv = x[rr];
         if (b.idx_b) {
-          const float4 y = ld4g(xb, c, cols);
-          x.x = __fadd_rn(__fmul_rn(b.lam, x.x), __fmul_rn(b.oml, y.x));
-          x.y = __fadd_rn(__fmul_rn(b.lam, x.y), __fmul_rn(b.oml, y.y));
-          x.z = __fadd_rn(__fmul_rn(b.lam, x.z), __fmul_rn(b.oml, y.z));
-          x.w = __fadd_rn(__fmul_rn(b.lam, x.w), __fmul_rn(b.oml, y.w));
+          xv.x = __fadd_rn(__fmul_rn(b.lam, xv.x), __fmul_rn(b.oml, y[rr].x));
+          xv.y = __fadd_rn(__fmul_rn(b.lam, xv.y), __fmul_rn(b.oml, y[rr].y));
+          xv.z = __fadd_rn(__fmul_rn(b.lam, xv.z), __fmul_rn(b.oml, y[rr].z));
+          xv.w = __fadd_rn(__fmul_rn(b.lam, xv.w), __fmul_rn(b.oml, y[rr].w));
         }
         float4 n;
-        if (noise_in) n = ld4g(noise_in + r * cols, c, cols);
+        if (noise_in) n = nz[rr];
         else n = randn4(seed, row_offset + (uint32_t)r, (uint32_t)q, 0u, TAG_QNOISE);
         float4 o;
-        o.x = __fadd_rn(__fmul_rn(a, x.x), __fmul_rn(bb, n.x));
-        o.y = __fadd_rn(__fmul_rn(a, x.y), __fmul_rn(bb, n.y));
-        o.z = __fadd_rn(__fmul_rn(a, x.z), __fmul_rn(bb, n.z));
-        o.w = __fadd_rn(__fmul_rn(a, x.w), __fmul_rn(bb, n.w));
+        o.x = __fadd_rn(__fmul_rn(a[rr], xv.x), __fmul_rn(bb[rr], n.x));
+        o.y = __fadd_rn(__fmul_rn(a[rr], xv.y), __fmul_rn(bb[rr], n.y));
+        o.z = __fadd_rn(__fmul_rn(a[rr], xv.z), __fmul_rn(bb[rr], n.z));
+        o.w = __fadd_rn(__fmul_rn(a[rr], xv.w), __fmul_rn(bb[rr], n.w));
         st4g(x_t + r * ldxt, c, cols, o);
         zero_pad(x_t + r * ldxt, cols, ldxt, c);
         if (noise_out && noise_out != noise_in) st4g(noise_out + r * cols, c, cols, n);
-        if (x0_out) st4g(x0_out + r * cols, c, cols, x);
+        if (x0_out) st4g(x0_out + r * cols, c, cols, xv);
       }
     }
   }
