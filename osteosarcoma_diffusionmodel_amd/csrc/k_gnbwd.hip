@@ -84,64 +84,32 @@ hipError_t launch_dgrad_gnbwd_dual(hipStream_t s, const GemmArgs& g1, int gw, co
 }
 
 // d gamma[c] += sum_r gy[r][c] * zhat[r][c], d beta[c] += sum_r gy[r][c] for every listed layer, one launch (targets zeroed by
-// the caller; float atomics over the 64-row blocks)
-__global__ __launch_bounds__(256) void k_gn_colsums(const GnColItem* __restrict__ items) {
+// the caller; float atomics over the 64-row blocks).  (Tried: 16-byte loads, eight rows in flight, the row lanes of a block reduced in
+// LDS before the atomics -- the kernel itself 41 -> 37 us, the STEP 0.915 -> 0.93 ms in two of three same-box runs: it runs on the side
+// stream beside the dgrad tail, and its fewer, fatter blocks get in that chain's way.  One atomic per thread instead: 98 us.)
+__global__ void k_gn_colsums(const GnColItem* __restrict__ items) {
   const GnColItem it = items[blockIdx.z];
   const int64_t r0 = (int64_t)blockIdx.y * 64;
   if (r0 >= it.rows) return;
   const int64_t r1 = r0 + 64 < it.rows ? r0 + 64 : it.rows;
   const int ngrp = it.C / it.gw;
-  // a thread owns 4 adjacent columns (16-byte loads; C % 4 == 0 and gw % 4 == 0: one statistics pair per quad) and every
-  // `lanes`-th row of the 64-row block, eight rows' loads in flight before the first is used
-  const int quads = it.C >> 2;
-  const int lanes = quads >= 256 ? 1 : 256 / quads;          // row lanes per block (quads is a power-of-two fraction of 256 here, else 1)
-  const int q = threadIdx.x % quads, rl = threadIdx.x / quads;
-  for (int qq = q; qq < quads; qq += 256) {                  // C > 1024 only: more than one quad per thread
-    const int c = 4 * qq;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < it.C; c += gridDim.x * blockDim.x) {
     const int grp = c / it.gw;
-    float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;
-    for (int64_t rb = r0 + rl; rb < r1; rb += 8 * lanes) {
-      float4 gy[8], z[8]; float2 st[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int64_t r = rb + (int64_t)j * lanes;
-        const int64_t rc = r < r1 ? r : r1 - 1;
-        gy[j] = ldg4(it.gy + rc * it.ldy + c);
-        z[j] = ldg4(it.z + rc * it.ldz + c);
-        st[j] = *reinterpret_cast<const float2*>(it.stats + (rc * ngrp + grp) * 2);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (rb + (int64_t)j * lanes >= r1) break;
-        sb.x += gy[j].x; sb.y += gy[j].y; sb.z += gy[j].z; sb.w += gy[j].w;
-        sg.x += gy[j].x * ((z[j].x - st[j].x) * st[j].y);
-        sg.y += gy[j].y * ((z[j].y - st[j].x) * st[j].y);
-        sg.z += gy[j].z * ((z[j].z - st[j].x) * st[j].y);
-        sg.w += gy[j].w * ((z[j].w - st[j].x) * st[j].y);
-      }
+    float sb = 0.f, sg = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+      const float gy = it.gy[r * it.ldy + c];
+      const float2 st = *reinterpret_cast<const float2*>(it.stats + (r * ngrp + grp) * 2);
+      const float zh = (it.z[r * it.ldz + c] - st.x) * st.y;
+      sb += gy;
+      sg += gy * zh;
     }
-    // the row lanes of the block meet in LDS: one atomic per column and BLOCK (same-address atomics serialise in L2 -- with one
-    // per thread, 256 instead of 64 per address, this kernel took 98 us instead of 41)
-    __shared__ float red[256 * 8];
-    float* mine = red + threadIdx.x * 8;
-    mine[0] = sb.x; mine[1] = sb.y; mine[2] = sb.z; mine[3] = sb.w; mine[4] = sg.x; mine[5] = sg.y; mine[6] = sg.z; mine[7] = sg.w;
-    __syncthreads();
-    if (rl == 0) {
-      float t[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) t[k] = 0.f;
-      for (int l = 0; l < lanes; ++l)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] += red[(l * quads + q) * 8 + k];
-      atomicAdd(it.dbeta + c, t[0]); atomicAdd(it.dbeta + c + 1, t[1]); atomicAdd(it.dbeta + c + 2, t[2]); atomicAdd(it.dbeta + c + 3, t[3]);
-      atomicAdd(it.dgamma + c, t[4]); atomicAdd(it.dgamma + c + 1, t[5]); atomicAdd(it.dgamma + c + 2, t[6]); atomicAdd(it.dgamma + c + 3, t[7]);
-    }
-    __syncthreads();
+    atomicAdd(it.dbeta + c, sb);
+    atomicAdd(it.dgamma + c, sg);
   }
 }
 hipError_t launch_gn_colsums(hipStream_t s, const GnColItem* d_items, int n_items, int64_t max_rows) {
   if (n_items <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_gn_colsums, dim3(1, (unsigned)((max_rows + 63) / 64), (unsigned)n_items), dim3(256), 0, s, d_items);
+  hipLaunchKernelGGL(k_gn_colsums, dim3(2, (unsigned)((max_rows + 63) / 64), (unsigned)n_items), dim3(256), 0, s, d_items);
   return hipGetLastError();
 }
 
