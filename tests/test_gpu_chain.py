@@ -226,22 +226,23 @@ def _get_option(m, name):
     return v.value
 
 
-def test_chain_spin_timeout_is_recovered_on_the_per_layer_kernels():
+@pytest.mark.parametrize("variant,n", [("workspace", 128), ("panel", 64)])
+def test_chain_spin_timeout_is_recovered_on_the_per_layer_kernels(variant, n):
     """models/diffusion.py:427-449 cannot fail.  One row tile and TWO workgroups: the second workgroup takes step 1 of the tile
     while the first is still inside step 0, so its dependency wait is certain; a spin budget of one tick (10 ns) makes that
     wait give up (CHAIN_TIMEOUT).  The synchronous call must notice, re-run the chain on the per-layer kernels from the same
     x_T / draws and return their result, with a warning instead of an error."""
-    T, n = 12, 128
+    T = 12
     m = _model(T, seed=6)
     gen = torch.Generator().manual_seed(4)
     cond = torch.randn(n, 3, generator=gen).cuda()
     x_T = torch.randn(n, 2000, generator=gen).cuda()
     ref, ref_mask = _run(m, cond, n, "graph", x_T=x_T, seed=31, row_offset=7)
-    m.sampler, m.chain_grid, m.chain_spin_budget = "chain", 2, 1
+    m.sampler, m.chain_variant, m.chain_grid, m.chain_spin_budget = "chain", variant, 2, 1
     assert _get_option(m, "chain_fallbacks") == 0
     with pytest.warns(UserWarning, match="re-run on the per-layer kernels"):
         out, mask = m.sample(cond, n, x_T=x_T, seed=31, row_offset=7, return_mutation_mask=True)
-    assert m.last_sampler == "graph"
+    assert m.last_sampler == "graph" and m.last_chain_variant == variant
     assert _get_option(m, "chain_fallbacks") == 1 and _get_option(m, "last_engine") == 0
     assert torch.equal(out, ref) and torch.equal(mask, ref_mask)
     # Philox x_T (regenerated from the seed for the second run)
@@ -252,7 +253,7 @@ def test_chain_spin_timeout_is_recovered_on_the_per_layer_kernels():
     assert torch.equal(out2, ref2) and _get_option(m, "chain_fallbacks") == 2
     # with a sane budget the same geometry (surplus workgroup waiting for its turn) completes on the chain kernel
     m.chain_spin_budget = 500_000_000
-    out3, _ = _run(m, cond, n, "chain", seed=32)
+    out3, _ = _run(m, cond, n, "chain", variant, seed=32)
     assert torch.equal(out3, ref2) and _get_option(m, "chain_fallbacks") == 2
 
 
