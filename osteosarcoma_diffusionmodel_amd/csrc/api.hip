@@ -12,6 +12,7 @@
 #include "fwd.h"
 #include "launch.h"
 #include "bwd_host.h"
+#include "split.h"
 
 namespace osd {
 
@@ -233,6 +234,7 @@ int refresh_derived(osd_handle* h, hipStream_t s, bool pack_in_w) {
   g.F = a.H0; g.P = a.T; g.K = a.time_dim;
   OSD_HIP(launch_linear(s, g, true, true, h->params[a.pm.tp_b], h->d_temb, a.H0, false, false));
   h->panel_wpk_valid = false;           // the LDS-resident chain repacks its fragment-ordered copies before its next run
+  h->split_valid = false;               // ... and the bf16x3 engine its weight planes
   if (!pack_in_w) return OSD_OK;        // a training step that reads input_proj.weight directly (the next osd_load_weights packs it)
   OSD_HIP(launch_copy2d(s, h->params[a.pm.in_w], a.D, h->w_in_packed, h->w_in_ld, a.H0, a.D));   // pad columns stay zero
   if (h->w_out_packed) {                       // D % 4 != 0: rows [D, Dp) stay zero
@@ -399,6 +401,7 @@ int osd_destroy(osd_handle* h) {
   if (h->wgrad_stream) e = hipStreamDestroy(h->wgrad_stream);
   cons_free_plan(&h->cons);
   chain_free(h);
+  split_free(h);
   wgrad_group_free(h);
   bwd_persist_free(h);
   if (h->fork_ev) e = hipEventDestroy(h->fork_ev);
@@ -433,6 +436,12 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "chain_variant")) {           // 0 auto, 1 workspace chain (chain.h), 2 LDS-resident chain (chain_panel.h) where the architecture fits
     if (value < 0 || value > 2) { set_error("chain_variant must be 0 (auto), 1 (workspace chain) or 2 (LDS-resident chain)"); return OSD_EINVAL; }
     h->chain_variant = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "precision")) {               // 0 fp32 MFMA (default), 1 bf16x3 split: fp32 accuracy on the bf16 matrix pipe (gemm_bf3.h)
+    if (value < 0 || value > 1) { set_error("precision must be 0 (fp32) or 1 (bf16x3 split)"); return OSD_EINVAL; }
+    if (value == 1 && !split_supported(h->arch)) { set_error("precision 1 (bf16x3 split) covers trunks of width 256 / 512 only"); return OSD_EUNSUPPORTED; }
+    h->precision = (int)value;
     return OSD_OK;
   }
   if (!strcmp(name, "chain_grid")) {
@@ -523,6 +532,7 @@ int osd_get_option(osd_handle* h, const char* name, int64_t* value) {
       {"grouped_wgrad", h->grouped_wgrad}, {"fused_gn_bwd", h->fused_gn_bwd}, {"wgrad_mid_flush", h->wgrad_mid_flush},
       {"input_splitk", h->input_splitk}, {"train_streams", h->two_stream_bwd ? 2 : 1}, {"persistent_bwd", h->persistent_bwd}, {"bwd_spin_budget", (int64_t)h->bwd_spin_budget},
       // read-only counters
+      {"precision", h->precision}, {"last_precision", h->last_precision}, {"split_supported", split_supported(h->arch) ? 1 : 0},
       {"chain_fallbacks", h->chain_fallbacks}, {"last_engine", h->last_engine},
       {"chain_variant", h->chain_variant}, {"last_chain_variant", h->last_chain_variant}, {"panel_chain_supported", panel_chain_supported(h) ? 1 : 0}};
   for (const auto& e : tab)
@@ -583,13 +593,19 @@ int osd_denoiser_forward(osd_handle* h, const float* x, const int32_t* t_index, 
   if (!t_index && (t_all < 0 || t_all >= a.T)) { set_error("t=%d outside [0,%d)", t_all, a.T); return OSD_EINVAL; }
   if (n == 0) return OSD_OK;
   OSD_HIP(hipSetDevice(h->cfg.device));
+  hipStream_t s = h->stream;
+  const int* t_idx = nullptr;
+  OSD_TRY(sanitize_t(h, s, t_index, n, &t_idx));
+  if (h->precision == 1 && !(flags & OSD_F_TRAIN_MODE) && !masks) {      // eval mode on the bf16 matrix pipe; dropout stays fp32
+    OSD_TRY(split_denoiser_forward(h, x, t_idx, t_all, cond, n, eps));
+    if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
+    return OSD_OK;
+  }
+  h->last_precision = 0;
   FwdWs ws;
   const int64_t need = carve_fwd(a, nullptr, n, false, &ws);
   OSD_TRY(ensure_arena(&h->main, need));
   carve_fwd(a, h->main.arena, n, false, &ws);
-  hipStream_t s = h->stream;
-  const int* t_idx = nullptr;
-  OSD_TRY(sanitize_t(h, s, t_index, n, &t_idx));
   OSD_TRY(run_cond(h, s, cond, n, ws));
   TrunkIn in{};
   in.x = x; in.ldx = a.D; in.n = n; in.t_index = t_idx; in.t_imm = t_all;
@@ -625,6 +641,12 @@ int osd_p_sample_step(osd_handle* h, const float* x_t, int32_t t, const float* c
   OSD_TRY(check_row_offset(row_offset, n));
   if (n == 0) return OSD_OK;
   OSD_HIP(hipSetDevice(h->cfg.device));
+  if (h->precision == 1 && !((flags & OSD_F_TRAIN_MODE) && h->cfg.dropout_p > 0.f)) {
+    OSD_TRY(split_p_sample_step(h, x_t, t, cond, z, n, seed, row_offset, x_out));
+    if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(h->stream));
+    return OSD_OK;
+  }
+  h->last_precision = 0;
   FwdWs ws;
   const int64_t need = carve_fwd(a, nullptr, n, false, &ws);
   OSD_TRY(ensure_arena(&h->main, need));
@@ -742,7 +764,11 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
   if (n == 0) return OSD_OK;
   OSD_HIP(hipSetDevice(h->cfg.device));
   OSD_TRY(chain_check_status(h));            // a previous chain-kernel run that gave up is reported here at the latest
-  h->last_engine = chain_pick_engine(h, n, flags);
+  // bf16x3 split precision: eval-mode chains on the per-layer launches of split.hip (dropout inside the chain stays fp32)
+  const bool split = h->precision == 1 && !((flags & OSD_F_TRAIN_MODE) && h->cfg.dropout_p > 0.f);
+  h->last_precision = split ? 1 : 0;
+  if (split) OSD_TRY(split_prepare(h, h->stream));
+  h->last_engine = split ? 0 : chain_pick_engine(h, n, flags);
   if (h->last_engine == 1 && noises && h->w_out_packed) h->last_engine = 0;      // injected draws at D % 4 != 0: guarded per-layer kernels
   bool fell_back = false;
   if (h->last_engine == 1) {
@@ -782,7 +808,8 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
   for (int64_t c = 0; c < n_chunks && rc == OSD_OK; ++c) {
     const int64_t r0 = c * chunk;
     const int64_t m = std::min<int64_t>(chunk, n - r0);
-    rc = chain_chunk(h, h->slots[c % n_slots], cond, n, r0, m, x_T, noises, seed, row_offset, x_out, mut_mask_out, flags);
+    if (split) rc = split_chain_chunk(h, h->slots[c % n_slots], cond, n, r0, m, x_T, noises, seed, row_offset, x_out, mut_mask_out, flags);
+    else rc = chain_chunk(h, h->slots[c % n_slots], cond, n, r0, m, x_T, noises, seed, row_offset, x_out, mut_mask_out, flags);
   }
   // join
   for (int i = 0; i < n_slots; ++i) {
@@ -883,6 +910,7 @@ int osd_op_linear(osd_handle* h, const float* x, const float* w, const float* b,
   if (!h || !x || !w || !y) { set_error("null argument"); return OSD_EINVAL; }
   OSD_TRY(check_rows(n));
   OSD_HIP(hipSetDevice(h->cfg.device));
+  if (h->precision == 1 && !silu && n > 0 && K > 0 && N > 0) return split_op_linear(h, x, w, b, n, K, N, y);
   GemmArgs g{};
   g.A = w; g.lda = K; g.B0 = x; g.ldb0 = K; g.K0 = K; g.F = N; g.P = (int)n; g.K = K;
   OSD_HIP(launch_linear(h->stream, g, true, true, b, y, N, silu != 0, false));

@@ -162,6 +162,12 @@ struct osd_handle {
   float* panel_wpk = nullptr; int64_t panel_wpk_floats = 0;   // fragment-ordered copies of the weights
   bool panel_wpk_valid = false;      // false after anything that may have changed the parameters: repacked by the next chain
   void* panel_args_dev = nullptr; void* panel_args_host = nullptr; int panel_args_cap = 0;
+  // bf16x3 split precision (gemm_bf3.h / split.hip)
+  int precision = 0;                 // osd_set_option("precision"): 0 fp32 MFMA (default; the reference's arithmetic), 1 bf16x3 split on the bf16 matrix pipe
+                                     // (fp32 accuracy, eval-mode sampling / forward of 256 / 512 wide trunks; everything else stays fp32)
+  int last_precision = 0;            // precision the most recent forward / p_sample / sample call computed in (osd_get_option)
+  void* split_plan = nullptr;        // weight planes (split.hip)
+  bool split_valid = false;          // false after anything that may have changed the parameters: repacked by the next split-precision call
   // osd_profile_step: when non-null, run_trunk records prof_events[prof_i++] after every launch
   std::vector<hipEvent_t>* prof_events = nullptr;
   int prof_i = 0;

@@ -248,6 +248,12 @@ class BiologyAwareDiffusionModel(nn.Module):
         # SyntheticPatientGenerator switches None to auto: its per-scenario batches are the reference's default workload
         self.input_splitk: Optional[int] = None
         self.last_sampler: Optional[str] = None           # engine the most recent sample() ran on
+        # arithmetic of the eval-mode forward / p_sample / sample GEMMs: None / "fp32" = v_mfma_f32_32x32x2_f32, the reference's F.linear in
+        # fp32 (models/diffusion.py:198-256; the default); "bf16x3" = every fp32 operand as three bf16 planes (exact) and six bf16 MFMAs
+        # per product with fp32 accumulation (csrc/gemm_bf3.h): fp32 accuracy -- the same stated tolerances -- at the bf16 matrix rate.
+        # Trunk widths 256 / 512 only; train-mode (dropout) calls and training stay fp32.
+        self.precision: Optional[str] = None
+        self.last_precision: Optional[str] = None         # what the most recent predict_noise / p_sample / sample computed in
         self.train_streams: Optional[int] = None      # 1 = whole backward on one stream, 2 (library default) = weight gradients on a side stream
         self.persistent_bwd: Optional[int] = None     # 1 = dgrad chain + weight gradients as one persistent launch (csrc/bwd_persist.h; library default 0)
         # optional constraint losses (set_constraints); None = the reference's eps-MSE only
@@ -353,6 +359,11 @@ class BiologyAwareDiffusionModel(nn.Module):
         except KeyError:
             raise ValueError(f"chain_variant must be None, 'auto', 'workspace' or 'panel', got {self.chain_variant!r}")
         L.check(L.lib().osd_set_option(eng.handle, b"chain_variant", variant))
+        try:
+            prec = {None: 0, "fp32": 0, "f32": 0, "bf16x3": 1}[self.precision]
+        except KeyError:
+            raise ValueError(f"precision must be None, 'fp32' or 'bf16x3', got {self.precision!r}")
+        L.check(L.lib().osd_set_option(eng.handle, b"precision", prec))
         for name, val in (("chain_grid", self.chain_grid), ("chain_steps_per_launch", self.chain_steps_per_launch),
                           ("chain_stagger", self.chain_stagger), ("chain_spin_budget", self.chain_spin_budget),
                           ("chain_wall_budget_ms", self.chain_wall_budget_ms), ("input_splitk", self.input_splitk)):
@@ -379,6 +390,11 @@ class BiologyAwareDiffusionModel(nn.Module):
         if n and (int(t32.min()) < 0 or int(t32.max()) >= self.num_steps):
             raise IndexError(f"timestep index out of range [0, {self.num_steps})")
         return t32
+
+    def _note_precision(self, eng) -> None:
+        v = C.c_int64(0)
+        L.check(L.lib().osd_get_option(eng.handle, b"last_precision", C.byref(v)))
+        self.last_precision = "bf16x3" if int(v.value) == 1 else "fp32"
 
     def _flags(self) -> int:
         return L.OSD_F_TRAIN_MODE if self.training else 0
@@ -441,9 +457,11 @@ class BiologyAwareDiffusionModel(nn.Module):
             from .train import denoiser_with_grad
             if t_idx is None:
                 t_idx = torch.full((n,), t_all, device=x_t.device, dtype=torch.int32)
+            self.last_precision = "fp32"          # the differentiable path keeps the activations of the fp32 kernels
             return denoiser_with_grad(self, x_t, t_idx, conditions, keep if dropout_masks is not None else None, seed, flags)
         L.check(L.lib().osd_denoiser_forward(eng.handle, L.ptr(x_t), L.ptr(t_idx), t_all, L.ptr(conditions), n,
                                              L.ptr(eps), flags, masks, seed))
+        self._note_precision(eng)
         return eps
 
     # -- p_sample / sample (models/diffusion.py:382-449) ------------------------------------------
@@ -458,6 +476,7 @@ class BiologyAwareDiffusionModel(nn.Module):
         seed = _draw_seed() if (seed is None and z is None) else (seed or 0)
         L.check(L.lib().osd_p_sample_step(eng.handle, L.ptr(x_t), int(t), L.ptr(conditions), L.ptr(z), n, seed, 0,
                                           L.ptr(out), self._flags()))
+        self._note_precision(eng)
         return out
 
     @torch.no_grad()
@@ -495,6 +514,7 @@ class BiologyAwareDiffusionModel(nn.Module):
         if used < 0:
             L.check(used)
         self.last_sampler = "chain" if used == 1 else "graph"
+        self._note_precision(eng)
         self.last_chain_variant = None
         if engine == 1:                      # which chain kernel ran (also set when its result was discarded for the re-run)
             import ctypes as C
