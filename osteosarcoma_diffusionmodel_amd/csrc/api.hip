@@ -828,6 +828,7 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
 int osd_sample_engine(osd_handle* h, int64_t n, int flags) {
   if (!h) { set_error("null handle"); return OSD_EINVAL; }
   if (n < 0) return h->last_engine;
+  if (h->precision == 1 && !((flags & OSD_F_TRAIN_MODE) && h->cfg.dropout_p > 0.f)) return 0;     // bf16x3: per-layer launches (split.hip)
   return chain_pick_engine(h, n, flags);
 }
 

@@ -33,21 +33,28 @@ struct SplitPlan {
   std::vector<uint4*> w_layer;        // 2 per block, execution order
 };
 
-template <class Epi>
+template <class Epi, int NKB>
 struct B3Registrar {
-  B3Registrar() { kernel_registry().push_back({reinterpret_cast<const void*>(gemm_bf3_kernel<Epi, B3_LD>), B3_LDS_BYTES}); }
+  B3Registrar() { kernel_registry().push_back({reinterpret_cast<const void*>(gemm_bf3_kernel<Epi, B3_LD, NKB>), B3_LDS_BYTES}); }
   static B3Registrar instance;
 };
-template <class Epi> B3Registrar<Epi> B3Registrar<Epi>::instance;
+template <class Epi, int NKB> B3Registrar<Epi, NKB> B3Registrar<Epi, NKB>::instance;
 
-template <class Epi>
+template <class Epi, int NKB = 0>
 static hipError_t launch_b3(hipStream_t s, const Bf3Args& g, const typename Epi::Args& ea) {
-  (void)&B3Registrar<Epi>::instance;
+  (void)&B3Registrar<Epi, NKB>::instance;
   if (g.F <= 0 || g.P <= 0) return hipSuccess;
   const int nft = (g.F + B3_ROWS - 1) / B3_ROWS, npt = (g.P + B3_ROWS - 1) / B3_ROWS;
   const int grid = ((npt + 7) / 8) * 8 * nft;
-  hipLaunchKernelGGL((gemm_bf3_kernel<Epi, B3_LD>), dim3(grid), dim3(NTHREADS + 64 * B3_LD), B3_LDS_BYTES, s, g, ea);
+  hipLaunchKernelGGL((gemm_bf3_kernel<Epi, B3_LD, NKB>), dim3(grid), dim3(NTHREADS + 64 * B3_LD), B3_LDS_BYTES, s, g, ea);
   return hipGetLastError();
+}
+// output_proj + posterior: the unrolled kernels (the normals are drawn inside the K loop) for 256 / 512 deep reductions
+static hipError_t launch_post(hipStream_t s, const Bf3Args& g, EpiB3Post::Args ea) {
+  ea.x_tile = (ea.ldx % 4 == 0 && g.F % 4 == 0 && g.F >= 4 && (reinterpret_cast<uintptr_t>(ea.x) & 15) == 0) ? 1 : 0;
+  if (g.nkb == 16) return launch_b3<EpiB3Post, 16>(s, g, ea);
+  if (g.nkb == 32) return launch_b3<EpiB3Post, 32>(s, g, ea);
+  return launch_b3<EpiB3Post, 0>(s, g, ea);
 }
 
 static hipError_t launch_pack(hipStream_t s, const float* src, int ld, int64_t R, int K, uint4* dst) {
@@ -199,7 +206,7 @@ int split_p_sample_step(osd_handle* h, const float* x_t, int32_t t, const float*
   ea.bias = h->params[a.pm.out_b]; ea.x = x_out; ea.ldx = a.D; ea.coef = h->d_coef; ea.t_dev = nullptr; ea.t_imm = t;
   ea.z = z; ea.ldzz = a.D; ea.z_step_stride = 0; ea.t_first = t; ea.seed = seed; ea.row_offset = (uint32_t)row_offset;
   ea.mut_mask = nullptr; ea.mutation_dim = 0; ea.o = B3Out{ws.xpl, b3_nkb(a.D)};
-  OSD_HIP(launch_b3<EpiB3Post>(s, split_out_args(h, ws, n), ea));
+  OSD_HIP(launch_post(s, split_out_args(h, ws, n), ea));
   h->last_precision = 1;
   return OSD_OK;
 }
@@ -241,7 +248,7 @@ int split_chain_chunk(osd_handle* h, Slot& sl, const float* cond, int64_t n_tota
     ea.seed = seed; ea.row_offset = roff;
     ea.mut_mask = mut_mask_out ? mut_mask_out + r0 * h->cfg.mutation_dim : nullptr; ea.mutation_dim = h->cfg.mutation_dim;
     ea.o = B3Out{ws.xpl, b3_nkb(D)};
-    OSD_HIP(launch_b3<EpiB3Post>(s, split_out_args(h, ws, m), ea));
+    OSD_HIP(launch_post(s, split_out_args(h, ws, m), ea));
     OSD_HIP(launch_add_int(s, sl.t_dev, -1));
     return OSD_OK;
   };

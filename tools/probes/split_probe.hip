@@ -18,9 +18,11 @@ using namespace osd;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 // empty epilogue: the K loop alone (one conditional store keeps the accumulators alive)
-struct EpiB3Null {
+struct EpiB3Null : EpiB3Base {
   struct Args { float* sink; };
-  static __device__ __forceinline__ void apply(f32x16 (&acc)[2][2], const Args& a, int, int, int, int, int lane, int, int) {
+  static __device__ __forceinline__ const float* prm_ptr(const Args&, int) { return nullptr; }
+  static __device__ __forceinline__ void apply(f32x16 (&acc)[2][2], const Args& a, const B3Ctx& c, B3NoState&) {
+    const int lane = c.lane;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -144,10 +146,10 @@ static void numerics(int F, int P, int K, bool positive_x, int ld) {
 }
 
 // one layer shape: K -> N over P rows; kind 0 = K loop alone, 1 = GroupNorm + SiLU (N = 256 / 512), 2 = output_proj + posterior (Philox)
-template <class Epi>
+template <class Epi, int NKB = 0>
 static void time_b3(int grid, int reps, const Bf3Args& g, const typename Epi::Args& ea, float* us) {
-  us[0] = time_kernel(gemm_bf3_kernel<Epi, 0>, grid, 256, B3_LDS_BYTES, reps, g, ea);
-  us[1] = time_kernel(gemm_bf3_kernel<Epi, 2>, grid, 384, B3_LDS_BYTES, reps, g, ea);
+  us[0] = time_kernel(gemm_bf3_kernel<Epi, 0, NKB>, grid, 256, B3_LDS_BYTES, reps, g, ea);
+  us[1] = B3_RING == 3 ? time_kernel(gemm_bf3_kernel<Epi, 2, NKB>, grid, 384, B3_LDS_BYTES, reps, g, ea) : us[0];      // the loader variant is written for three slots
 }
 static void rate(int K, int N, int P, int kind, int reps) {
   const int Kp = (K + 31) / 32 * 32;
@@ -157,7 +159,7 @@ static void rate(int K, int N, int P, int kind, int reps) {
   CK(hipMalloc(&dPar, (size_t)3 * 4096 * 4)); CK(hipMalloc(&dOut, (size_t)P * N * 4)); CK(hipMalloc(&dSink, 4096)); CK(hipMalloc(&dCoef, 4096 * 16));
   CK(hipMalloc(&dXs, (size_t)P * N * 4));
   const int grid = grid_for(N, P);
-  CK(hipMalloc(&dSt, (size_t)grid * 16));
+  CK(hipMalloc(&dSt, (size_t)grid * 32));
   {
     std::vector<float> h((size_t)N * Kp);
     std::mt19937 rng(7);
@@ -189,15 +191,15 @@ static void rate(int K, int N, int P, int kind, int reps) {
     time_b3<EpiB3Null>(grid, reps, g, EpiB3Null::Args{dSink}, us3);
     us32 = time_kernel(gemm_glds_kernel<TileBig, EpiNull32>, grid, 256, l32, reps, g32, EpiNull32::Args{dSink});
     // shader clock during the K loop: s_memtime cycles per s_memrealtime tick (100 MHz), median workgroup
-    for (int ld = 0; ld < 2; ++ld) {
+    for (int ld = 0; ld < (B3_RING == 3 ? 2 : 1); ++ld) {
       Bf3Args gs = g; gs.stamps = dSt;
       if (ld == 0) hipLaunchKernelGGL((gemm_bf3_kernel<EpiB3Null, 0>), dim3(grid), dim3(256), B3_LDS_BYTES, 0, gs, EpiB3Null::Args{dSink});
       else hipLaunchKernelGGL((gemm_bf3_kernel<EpiB3Null, 2>), dim3(grid), dim3(384), B3_LDS_BYTES, 0, gs, EpiB3Null::Args{dSink});
       CK(hipDeviceSynchronize());
-      std::vector<unsigned long long> st((size_t)grid * 2);
+      std::vector<unsigned long long> st((size_t)grid * 4);
       CK(hipMemcpy(st.data(), dSt, st.size() * 8, hipMemcpyDeviceToHost));
       std::vector<double> f;
-      for (int b = 0; b < grid; ++b) if (st[2 * b + 1] > 0) f.push_back((double)st[2 * b] / (double)st[2 * b + 1] * 0.1);
+      for (int b = 0; b < grid; ++b) if (st[4 * b + 1] > 0) f.push_back((double)st[4 * b] / (double)st[4 * b + 1] * 0.1);
       std::sort(f.begin(), f.end());
       ghz[ld] = f.empty() ? 0 : f[f.size() / 2];
     }
@@ -216,9 +218,38 @@ static void rate(int K, int N, int P, int kind, int reps) {
   } else {
     name = "posterior+Philox";
     EpiB3Post::Args e{}; e.bias = dPar; e.x = dXs; e.ldx = N; e.coef = dCoef; e.t_imm = 500; e.seed = 1; e.o = B3Out{pO, b3_nkb(N)};
-    time_b3<EpiB3Post>(grid, reps, g, e, us3);
+    e.x_tile = (N % 4 == 0 && B3_RING == 3) ? 1 : 0;
+    if (K == 256) time_b3<EpiB3Post, 16>(grid, reps, g, e, us3);
+    else time_b3<EpiB3Post, 0>(grid, reps, g, e, us3);
+    {   // the same launch with the direct x accesses and the generator behind the loop (the first version of this epilogue)
+      float u2[2];
+      e.x_tile = 0;
+      time_b3<EpiB3Post, 0>(grid, reps, g, e, u2);
+      printf("     (posterior with direct x accesses and the generator in the epilogue: LD0 %.1f us, LD2 %.1f us)\n", u2[0], u2[1]);
+    }
     EpiPosterior::Args e2{}; e2.bias = dPar; e2.xin = dXs; e2.ldx = N; e2.xout = dXs; e2.ldo = N; e2.coef = dCoef; e2.t_imm = 500; e2.ldzz = N; e2.seed = 1; e2.t_first = 500;
     us32 = time_kernel(gemm_glds_kernel<TileBig, EpiPosterior>, grid, 256, l32, reps, g32, e2);
+  }
+  if (kind != 0) {
+    Bf3Args gs = g; gs.stamps = dSt;
+    CK(hipMemset(dSt, 0, (size_t)grid * 32));
+    if (kind == 1) {
+      B3Out o{pO, b3_nkb(N)};
+      if (N / 8 == 64) hipLaunchKernelGGL((gemm_bf3_kernel<EpiB3Gn<64>, 0, 0>), dim3(grid), dim3(256), B3_LDS_BYTES, 0, gs, EpiB3Gn<64>::Args{dPar, dPar + 4096, dPar + 8192, o});
+      else hipLaunchKernelGGL((gemm_bf3_kernel<EpiB3Gn<32>, 0, 0>), dim3(grid), dim3(256), B3_LDS_BYTES, 0, gs, EpiB3Gn<32>::Args{dPar, dPar + 4096, dPar + 8192, o});
+    } else {
+      EpiB3Post::Args e{}; e.bias = dPar; e.x = dXs; e.ldx = N; e.coef = dCoef; e.t_imm = 500; e.seed = 1; e.o = B3Out{pO, b3_nkb(N)}; e.x_tile = B3_RING == 3 ? 1 : 0;
+      if (K == 256) hipLaunchKernelGGL((gemm_bf3_kernel<EpiB3Post, 0, 16>), dim3(grid), dim3(256), B3_LDS_BYTES, 0, gs, e);
+      else hipLaunchKernelGGL((gemm_bf3_kernel<EpiB3Post, 0, 0>), dim3(grid), dim3(256), B3_LDS_BYTES, 0, gs, e);
+    }
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> st((size_t)grid * 4);
+    CK(hipMemcpy(st.data(), dSt, st.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> kc, ec;
+    for (int b = 0; b < grid; ++b) if (st[4 * b + 1] > 0) { kc.push_back((double)st[4 * b]); ec.push_back((double)st[4 * b + 2]); }
+    std::sort(kc.begin(), kc.end()); std::sort(ec.begin(), ec.end());
+    if (!kc.empty()) printf("     stamps (LD0, median workgroup): prologue + K loop %.0f cycles, epilogue + drain %.0f cycles (MFMA time of the tile alone: %d)\n",
+                            kc[kc.size() / 2], ec[ec.size() / 2], b3_nkb(K) * 768);
   }
   const double flop = 2.0 * K * N * (double)P;
   printf("rate K=%4d N=%4d P=%d %-16s: bf16x3 LD0 %7.1f us %6.1f TF | LD2 %7.1f us %6.1f TF (%.3f of 417) | fp32 %7.1f us %6.1f TF (%.3f of 157.3) | speedup %.2fx / %.2fx", K, N, P,
@@ -231,6 +262,10 @@ static void rate(int K, int N, int P, int kind, int reps) {
 
 int main(int argc, char** argv) {
   const int P = argc > 1 ? atoi(argv[1]) : 65536;
+  if (argc > 2 && argv[2][0] == 'p') {      // the posterior launch only
+    rate(256, 2000, P, 2, 20);
+    return 0;
+  }
   if (argc > 2) {           // K loops only (the -DB3_EXP=n timing variants)
     rate(512, 512, P, 0, 20);
     rate(256, 256, P, 0, 20);
@@ -238,7 +273,7 @@ int main(int argc, char** argv) {
     rate(256, 2000, P, 0, 20);
     return 0;
   }
-  for (int ld = 0; ld <= 2; ld += 2) {
+  for (int ld = 0; ld <= (B3_RING == 3 ? 2 : 0); ld += 2) {
     numerics(512, 256, 256, true, ld);
     numerics(512, 256, 512, true, ld);
     numerics(256, 200, 2000, false, ld);
