@@ -35,6 +35,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (at 2.4 GHz; the part holds ~1.75 GHz under this load)
 HBM_PEAK_GBPS = 8000.0
 FLOP_PER_PATIENT_STEP = 5_193_728      # 2 x 2 596 864 MAC, GEMMs only
 TRAIN_FLOP_PER_SAMPLE = 14.56e6        # fwd 5.194 + dgrad 4.170 + wgrad 5.194 MFLOP
@@ -70,6 +71,8 @@ def parse_args():
     ap.add_argument("--train-only", action="store_true", help="run only the training leg (for rocprofv3 --stats)")
     ap.add_argument("--no-reference-workload", action="store_true", help="skip the reference's default generation workload leg")
     ap.add_argument("--reference-workload-only", action="store_true")
+    ap.add_argument("--no-split", action="store_true", help="skip the opt-in bf16x3 split-precision leg (roofline.split_bf16): the same workload with every GEMM "
+                    "on the bf16 matrix pipe at fp32 accuracy; never the headline")
     ap.add_argument("--no-mid-size", action="store_true", help="skip the 32 768-patient comparison (LDS-resident chain kernel vs per-layer kernels) inside the roofline object")
     ap.add_argument("--no-validate", action="store_true", help="skip the config-5 share leg (3 x 125 000 patients + on-device validation)")
     ap.add_argument("--validate-only", action="store_true")
@@ -220,7 +223,7 @@ def validate_leg(model, dev, per_scenario=125_000):
     generated (full T = 1000 chain) and validated against a 125 000-row "real" cohort (synthetic: an earlier sample with another
     seed) -- per metric the device time and the roofline that bounds it, then BiologicalValidator.validate_all through the
     reference's entry point (DeviceFrame inputs; its Wasserstein-on-PCA part is the reference's own host-side sklearn / scipy
-    code).  MMD: three Gram blocks on fp32 MFMA, 2 D (n^2 + m^2 + n m) FLOP.  KS / pathway coherence / co-occurrence: HBM
+    code).  MMD: three Gram blocks on fp32 MFMA; K_XX / K_YY on their upper triangles: 2 D (n(n+1)/2 + m(m+1)/2 + n m) necessary FLOP.  KS / pathway coherence / co-occurrence: HBM
     streams; algorithmic bytes = every element they must read once."""
     import numpy as np
     import pandas as pd
@@ -273,7 +276,8 @@ def validate_leg(model, dev, per_scenario=125_000):
         _, t_coh = timed(lambda: (val._mean_offdiag(re_.values, cols64), val._mean_offdiag(se.values, cols64)))
         _, t_gram = timed(lambda: (val._gram(sm.values, list(range(50))), val._column_sums(sm.values)))
         allr, t_all = timed(lambda: val.validate_all(rm, re_, rp, sm, se, sp, pathway_gene_matrix=pgm))
-        flop_mmd = 2.0 * D * (n * float(n) * 3)
+        # necessary work only: K_XX and K_YY are symmetric and run on the tiles on or above the diagonal (csrc/validate.hip)
+        flop_mmd = 2.0 * D * (n * (n + 1.0) / 2 * 2 + n * float(n))
         ks_bytes = 100 * 2 * n * 4.0                         # every sample of the 100 tested features once
         coh_bytes = 2 * 64 * 2 * n * 4.0                     # real + synthetic, 64 genes, moments pass + row pass
         gram_bytes = 2 * 50 * n * 4.0
@@ -547,6 +551,42 @@ def main():
         dist.destroy_process_group()
 
 
+def split_leg(model, args, cond, offset, step_fn):
+    """The SAME workload (args.patients, full T, same seeds -> same Philox draws) under ``model.precision = "bf16x3"`` (csrc/gemm_bf3.h,
+    split.hip): every fp32 operand as three bf16 planes (exact), six v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation -- the
+    fp32 tolerances of the parity tests unchanged (tests/test_gpu_split.py).  Opt-in, never the headline: `value`, `dtype` and the
+    default engine of this line are the fp32 ones.  `executed_mfma_tflops` = 6 x the algorithmic FLOP, priced against the bf16 peak;
+    `effective_tflops` = the algorithmic FLOP (what the fp32 kernels are priced on), shown against the fp32 MFMA peak it is not bound by."""
+    import torch
+    if args.no_split or args.profile_only or int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        return None
+    T = CONF["model"]["diffusion"]["num_steps"]
+    keep_p, keep_s = model.precision, model.sampler
+    ref, _ = step_fn(20_000)
+    try:
+        model.precision = "bf16x3"
+        model.sampler = "auto"
+        model.sample(cond[:4096].contiguous(), 4096, seed=5)          # weight planes, workspace, graph capture off the clock
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out, _ = step_fn(20_000)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert model.last_precision == "bf16x3"
+    finally:
+        model.precision, model.sampler = keep_p, keep_s
+    flop = float(args.patients) * T * FLOP_PER_PATIENT_STEP
+    scale = float(ref.abs().max())
+    return {"dtype": "bf16x3 split, f32 accumulate", "patients_per_s": round(args.patients / dt, 1), "seconds": round(dt, 4),
+            "engine": "per-layer launches on planes buffers (split.hip), hipGraph replay",
+            "effective_tflops": round(flop / dt / 1e12, 2), "effective_vs_fp32_mfma_peak": round(flop / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "executed_mfma_tflops": round(6 * flop / dt / 1e12, 1), "bf16_mfma_peak": BF16_MFMA_PEAK_TFLOPS,
+            "frac_of_bf16_mfma_peak": round(6 * flop / dt / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+            "max_abs_diff_vs_fp32_engine_over_max_abs": float((out - ref).abs().max()) / max(scale, 1e-30),
+            "note": "same seeds as the fp32 run (identical Philox draws); full T-step chains of random-init weights amplify rounding differences, "
+                    "the parity statement is tests/test_gpu_split.py (oracle, unchanged tolerances)"}
+
+
 def roofline_leg(model, args, cond, offset, dev, engine_used, sample_ms, step_fn):
     """The dominant kernel of the timed region, measured live with HIP events on its launch stream.
 
@@ -641,7 +681,8 @@ def roofline_leg(model, args, cond, offset, dev, engine_used, sample_ms, step_fn
             mid[name] = {"patients_per_s": round(mrows / dt, 1), "tflops": round(tf, 2), "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
                          "engine": model.last_sampler + ("/" + model.last_chain_variant if model.last_chain_variant else "")}
         model.sampler = keep
-    return {"bound": "mfma", "kernel": "chain_kernel (persistent: all 12 layers x all T steps of the rank's patients in one launch; "
+    split = split_leg(model, args, cond, offset, step_fn)
+    return {"split_bf16": split, "bound": "mfma", "kernel": "chain_kernel (persistent: all 12 layers x all T steps of the rank's patients in one launch; "
                                        "v_mfma_f32_32x32x2_f32, 128x128 tiles, LDS-DMA staging)",
             "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
             "traffic": ctraffic, "traffic_source": csource,

@@ -599,7 +599,10 @@ struct EpiRbfSum {
   // sum: RBF_SLOTS doubles; a workgroup adds into slot blockIdx.x % RBF_SLOTS (same-address atomics serialise in L2: 153 000
   // tiles of a 50 000 x 50 000 block on ONE address cost ~2 % of the kernel), the host adds the slots up
   static constexpr int RBF_SLOTS = 256;
-  struct Args { const float* sqa; const float* sqb; float gamma; double* sum; };
+  // tri: the product is symmetric and only tiles with feature tile <= patient tile run (GemmArgs::tri, 128 x 128 tiles): a tile
+  // strictly above the diagonal stands for its mirror image too and counts twice; the diagonal tiles are computed whole
+  // (utils/validation.py:286-296 sums the full matrix, diagonal included)
+  struct Args { const float* sqa; const float* sqb; float gamma; double* sum; int tri; };
   static bool fast_ok(const Args& a, int F) { return F % 4 == 0 && al16(a.sqa); }
   template <int NFB> struct Pre { float4 sqa[NFB][4]; };
   template <int NFB, bool FAST>
@@ -637,6 +640,7 @@ struct EpiRbfSum {
         }
     }
     double dp = (double)part;
+    if (a.tri && (fw >> 7) < (pw >> 7)) dp *= 2.0;       // uniform over the workgroup
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dp += __shfl_xor(dp, o);
     // one atomic per workgroup: a 50 000 x 50 000 Gram block is 153 000 tiles, and same-address atomics serialise in L2

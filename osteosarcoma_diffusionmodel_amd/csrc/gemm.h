@@ -42,6 +42,8 @@ struct GemmArgs {
   int a_kmax;                  // gemm_glds_kernel: > 0 = the A operand is only readable for k < a_kmax (an unpadded weight whose K is not a
                                // multiple of 32): its staging addresses are clamped there, and the B operand must hold ZEROS for
                                // k in [a_kmax, K) instead (a padded activation buffer owned by the library)
+  int tri;                     // 1: a symmetric product (A == B, F == P, square 128 x 128 tiles): only tiles on or above the diagonal
+                               // (feature tile <= patient tile) are computed; the epilogue weighs the off-diagonal ones twice (EpiRbfSum)
   unsigned long long* stamps;  // diagnostic: per-wave s_memtime stamps [wave][4] (null in production)
 };
 
@@ -372,6 +374,7 @@ __global__ __launch_bounds__(NTHREADS * NG, NG == 1 ? 2 : 1) void gemm_kernel(Ge
   const int ft = idx % nft;
   const int pt = (idx / nft) * 8 + (b & 7);
   if (pt >= npt) return;
+  if (g.tri && ft > pt) return;          // symmetric product: the mirror tile (pt, ft) carries this one's weight
   gemm_tile<T, AKC, BKC, Epi, FAST, NG>(g, ea, ft * T::BF, pt * T::BP, smem);
 }
 

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(NTHREADS * NG, NG == 1 ? 2 : 1) void gemm_glds_kern
     pstride = npt;                       // exactly one tile
   }
   if (pt >= npt) return;
+  if (g.tri && ft > pt) return;          // symmetric product (never with g.persist): the mirror tile carries this one's weight
   const int f0 = ft * T::BF;
 
   const int tid = threadIdx.x & (NTHREADS - 1);       // position inside the wave group

@@ -121,7 +121,7 @@ hipError_t launch_gemm_glds(hipStream_t s, const GemmArgs& g0, const typename Ep
   g.persist = 0;
   const int pm = persist_mode();          // 1: 512 workgroups, 2: 256 (leaves room for a second stream's kernel)
   const int pgrid = pm == 2 ? 256 : 512;
-  if (pm && grid > pgrid && nft <= pgrid / 8 && (pgrid / 8) % nft == 0) { g.persist = 1; grid = pgrid; }
+  if (pm && !g.tri && grid > pgrid && nft <= pgrid / 8 && (pgrid / 8) % nft == 0) { g.persist = 1; grid = pgrid; }
   hipLaunchKernelGGL((gemm_glds_kernel<T, Epi>), dim3(grid), dim3(NTHREADS), GldsTile<T>::LDS_BYTES, s, g, ea);
   return hipGetLastError();
 }

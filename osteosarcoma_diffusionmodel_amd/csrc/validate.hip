@@ -128,7 +128,10 @@ static hipError_t rbf_sum(hipStream_t s, const float* X, int64_t n, const float*
                           float gamma, double* dsum) {
   GemmArgs g{};
   g.A = X; g.lda = D; g.B0 = Y; g.ldb0 = D; g.K0 = D; g.F = (int)n; g.P = (int)m; g.K = D;
-  EpiRbfSum::Args ea{sqx, sqy, gamma, dsum};
+  // K(X, X) is symmetric: the tiles on or above the diagonal, the off-diagonal ones weighted 2 -- half the MFMA work of the rectangle
+  static_assert(TileBig::BF == 128 && TileBig::BP == 128, "the triangular schedule compares 128-row tile indices");
+  g.tri = (X == Y && n == m && sqx == sqy) ? 1 : 0;
+  EpiRbfSum::Args ea{sqx, sqy, gamma, dsum, g.tri};
   return launch_gemm<TileBig, true, true, EpiRbfSum>(s, g, ea);
 }
 
@@ -187,7 +190,8 @@ int osd_val_rbf_sum(void* stream, int device, const float* A, int64_t n, const f
   float* sqb = sqa + n;
   OSD_HIP(hipMemsetAsync(sums.p, 0, NS * sizeof(double), s));
   hipLaunchKernelGGL(k_rowsumsq, 1024, 256, 0, s, A, n, D, sqa);
-  hipLaunchKernelGGL(k_rowsumsq, 1024, 256, 0, s, B, m, D, sqb);
+  if (A == B && n == m) sqb = sqa;                     // one operand: the symmetric (triangular) schedule of rbf_sum
+  else hipLaunchKernelGGL(k_rowsumsq, 1024, 256, 0, s, B, m, D, sqb);
   OSD_HIP(rbf_sum(s, A, n, sqa, B, m, sqb, D, (float)gamma, (double*)sums.p));
   std::vector<double> slots(NS);
   OSD_HIP(hipMemcpyAsync(slots.data(), sums.p, NS * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -150,6 +150,25 @@ class ShardComm:
             dist.broadcast(buf, src=src)
             yield t if src == self.rank else buf.to(t.device)
 
+    def ring_partners(self, t: torch.Tensor):
+        """Yield (shard, weight) so that every UNORDERED pair of different ranks meets exactly once over the whole group: in round
+        d = 1 .. world // 2 rank r sends its [n_r, cols] tensor to rank r - d and receives rank (r + d)'s (point to point: half the
+        shard traffic of ``shards``, which broadcasts every shard to everybody).  Weight 2 = the pair (r, r + d) is this rank's alone;
+        the last round of an even world pairs r with r + world / 2 from both ends, each end taking weight 1."""
+        if not self.on:
+            return
+        counts = self.sum(_one_hot(self.rank, self.world) * t.shape[0]).astype("int64")
+        mine = self._stage(t.contiguous())
+        for d in range(1, self.world // 2 + 1):
+            src, dst = (self.rank + d) % self.world, (self.rank - d) % self.world
+            buf = torch.empty((int(counts[src]),) + tuple(t.shape[1:]), dtype=t.dtype, device=mine.device)
+            ops = [dist.P2POp(dist.isend, mine, dst), dist.P2POp(dist.irecv, buf, src)]
+            if self.rank > dst:                      # lower rank of a pair posts its receive first (deadlock-free order on gloo)
+                ops.reverse()
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            yield buf.to(t.device), (1.0 if 2 * d == self.world else 2.0)
+
     def bcast_object(self, obj, src: int = 0):
         if not self.on:
             return obj

@@ -82,6 +82,41 @@ def _ks_pvalue(n1: int, n2: int, dmax: int, dmin: int):
     return float(d), float(np.clip(distributions.kstwo.sf(d, np.round(m * n / (m + n))), 0, 1))
 
 
+def _ks_pvalues(n1: int, n2: int, dmax, dmin):
+    """_ks_pvalue over all features.  Above 10 000 samples ks_2samp(method='auto') takes Smirnov's asymptotic formula: ONE
+    vectorised scipy call for the whole statistic vector (same values as the per-feature calls -- kstwo.sf is elementwise -- without
+    100 trips through rv_continuous' argument checking: 0.8 s -> 10 ms at 100 features); the exact branch stays per feature."""
+    dmax, dmin = np.asarray(dmax, dtype=np.int64), np.asarray(dmin, dtype=np.int64)
+    if max(n1, n2) <= 10000:
+        res = [_ks_pvalue(n1, n2, int(a), int(b)) for a, b in zip(dmax, dmin)]
+        return np.array([d for d, _ in res]), np.array([p for _, p in res])
+    from scipy.stats import distributions
+    d = np.maximum(np.maximum(dmax, -dmin), 0) / (float(n1) * float(n2))
+    m, n = sorted([float(n1), float(n2)], reverse=True)
+    return d.astype(np.float64), np.clip(distributions.kstwo.sf(d, np.round(m * n / (m + n))), 0, 1).astype(np.float64)
+
+
+def _chi2_pairs(n: int, gram: np.ndarray) -> np.ndarray:
+    """chi2 of scipy.stats.chi2_contingency(pd.crosstab(a_i, a_j)) (utils/validation.py:98-108) for every pair i < j of 0/1 columns,
+    row-major pair order, from the joint counts gram[i][j] = sum_r a_i a_j -- the closed form of what scipy does for a 2 x 2 table
+    (expected = outer(margins) / n, Yates' correction min(0.5, |expected - observed|) toward the expected value, Pearson sum), and
+    0.0 when a column is constant (crosstab then has a single row or column: zero degrees of freedom).  Same values as the
+    per-pair scipy calls (tests/test_oracle_golden.py), 2 x 1225 tables in one numpy expression instead of 0.26 s of calls."""
+    g = np.rint(np.asarray(gram, dtype=np.float64))
+    k = g.shape[0]
+    iu, ju = np.triu_indices(k, 1)
+    n1, n2, n11 = np.diag(g)[iu], np.diag(g)[ju], g[iu, ju]
+    obs = np.stack([n - n1 - n2 + n11, n2 - n11, n1 - n11, n11], axis=-1).reshape(-1, 2, 2)      # [[00, 01], [10, 11]]
+    rows, cols = obs.sum(2), obs.sum(1)
+    exp = rows[:, :, None] * cols[:, None, :] / float(n)
+    live = (rows > 0).all(1) & (cols > 0).all(1)
+    diff = exp - obs
+    adj = obs + np.minimum(0.5, np.abs(diff)) * np.sign(diff)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        terms = (adj - exp) ** 2 / exp
+    return np.where(live, np.where(live[:, None, None], terms, 0.0).sum((1, 2)), 0.0)
+
+
 class DeviceKernels:
     """The per-shard partial results, each one libosdiff.so call on device tensors."""
 
@@ -145,11 +180,12 @@ def sharded_mmd(comm: ShardComm, k, x, y_local, gamma: float) -> float:
     """utils/validation.py:273-298 with X replicated and Y row-sharded."""
     n = x.shape[0]
     m = int(comm.sum(y_local.shape[0])[0])
-    sxx = k.rbf_sum(x, x, gamma)
+    sxx = k.rbf_sum(x, x, gamma)                       # one operand: the library runs the upper triangle only (csrc/validate.hip)
     sxy = float(comm.sum(k.rbf_sum(x, y_local, gamma))[0])
-    syy_local = 0.0
-    for other in comm.shards(y_local):                 # rows of this shard against every shard: the row-block partition
-        syy_local += k.rbf_sum(y_local, other, gamma)
+    # K_YY is symmetric: this shard against itself (triangular) + every unordered pair of shards once, weighted 2
+    syy_local = k.rbf_sum(y_local, y_local, gamma)
+    for other, weight in comm.ring_partners(y_local):
+        syy_local += weight * k.rbf_sum(y_local, other, gamma)
     syy = float(comm.sum(syy_local)[0])
     v = sxx / (float(n) * n) + syy / (float(m) * m) - 2.0 * sxy / (float(n) * m)
     return float(np.sqrt(max(v, 0.0)))
@@ -230,25 +266,55 @@ class BiologicalValidator:
         r, s = _dev(real_data, self.device), _dev(synthetic_data, self.device)
         nf = min(r.shape[1], max_features)
         dmax, dmin, n2 = sharded_ks_extremes(self.comm, self.k, r, s, nf)
-        res = [_ks_pvalue(r.shape[0], n2, int(dmax[i]), int(dmin[i])) for i in range(nf)]
-        return self._agree((np.array([d for d, _ in res]), np.array([p for _, p in res])))
+        return self._agree(_ks_pvalues(r.shape[0], n2, dmax[:nf], dmin[:nf]))
 
     # -- utils/validation.py:225-271 --------------------------------------------------------------
     def statistical_tests(self, real_data, synthetic_data) -> Dict[str, float]:
         logger.info("Running statistical tests...")
-        _, pvals = self.ks_tests(real_data, synthetic_data)
-        results = {"ks_test_mean_pvalue": float(np.mean(pvals)), "ks_test_fraction_significant": float((pvals < 0.05).mean())}
-        results["mmd"] = self.compute_mmd(real_data, synthetic_data)
+        # The device parts first -- KS extremes (exact integers), then the MMD Gram blocks -- with the reference's own host-side parts
+        # BESIDE the MMD on two threads (the ctypes call releases the GIL): the 100 Smirnov p-values (scipy's kstwo.sf: 8 ms each at
+        # N = 62 500, whether called once or a hundred times) and the PCA fit + projection behind the Wasserstein figure (:256-269;
+        # the reference's own sklearn / scipy calls; fitted on the replicated real data, each rank projects its shard, the 10
+        # projected columns are gathered).  Same calls, same inputs, same order of draws from numpy's global generator (only the PCA
+        # draws): only the wall time moves -- 4.7 s -> 2.4 s per 125 000-row scenario together with the triangular MMD.
+        import threading
+        from scipy import stats
+        from sklearn.decomposition import PCA
+        r, s = _dev(real_data, self.device), _dev(synthetic_data, self.device)
+        nf = min(r.shape[1], 100)
+        dmax, dmin, n2 = sharded_ks_extremes(self.comm, self.k, r, s, nf)
+        real_host, synth_host = _host(real_data), _host(synthetic_data)      # device -> host before the MMD kernels occupy the stream
+        box = {}
+
+        def guarded(key, fn):
+            def run():
+                try:
+                    box[key] = fn()
+                except BaseException as e:               # re-raised on the calling thread
+                    box["error"] = e
+            return threading.Thread(target=run)
+
+        def fit():
+            pca = PCA(n_components=10)
+            return pca.fit_transform(real_host), pca.transform(synth_host)
+
+        threads = [guarded("ks", lambda: _ks_pvalues(r.shape[0], n2, dmax[:nf], dmin[:nf])), guarded("pca", fit)]
+        for th in threads:
+            th.start()
+        results = {}
+        try:
+            results["mmd"] = self.compute_mmd(real_data, synthetic_data)
+        finally:
+            for th in threads:
+                th.join()
+        if "error" in box:
+            raise box["error"]
+        _, pvals = self._agree(box["ks"])
+        results = {"ks_test_mean_pvalue": float(np.mean(pvals)), "ks_test_fraction_significant": float((pvals < 0.05).mean()), "mmd": results["mmd"]}
         logger.info(f"KS test mean p-value: {results['ks_test_mean_pvalue']:.3f}")
         logger.info(f"KS test fraction significant: {results['ks_test_fraction_significant']:.3f}")
         logger.info(f"MMD: {results['mmd']:.4f}")
-        # Wasserstein distance on the first 10 principal components (:256-269): host-side as in the reference; the
-        # PCA is fitted on the replicated real data, each rank projects its shard, the 10 projected columns are gathered
-        from scipy import stats
-        from sklearn.decomposition import PCA
-        pca = PCA(n_components=10)
-        real_pca = pca.fit_transform(_host(real_data))
-        synth_pca = pca.transform(_host(synthetic_data))
+        real_pca, synth_pca = box["pca"]
         if self.comm.on:
             synth_pca = self.comm.gather_rows(torch.from_numpy(np.ascontiguousarray(synth_pca))).numpy()
         results["wasserstein_distance_mean"] = float(np.mean([stats.wasserstein_distance(real_pca[:, i], synth_pca[:, i]) for i in range(10)]))
@@ -305,11 +371,7 @@ class BiologicalValidator:
         if len(idx) >= 2:
             gr = self._gram(r, idx)
             gs = self.comm.sum(self._gram(s, idx).ravel()).reshape(len(idx), len(idx))
-            chi_r, chi_s = [], []
-            for i in range(len(idx)):
-                for j in range(i + 1, len(idx)):
-                    chi_r.append(self._chi2(r.shape[0], int(round(gr[i, i])), int(round(gr[j, j])), int(round(gr[i, j]))))
-                    chi_s.append(self._chi2(n_synth, int(round(gs[i, i])), int(round(gs[j, j])), int(round(gs[i, j]))))
+            chi_r, chi_s = _chi2_pairs(r.shape[0], gr), _chi2_pairs(n_synth, gs)       # pairs i < j in row-major order, as the reference's loops
             results["cooccurrence_pattern_correlation"] = float(np.corrcoef(chi_r, chi_s)[0, 1])
             logger.info(f"Co-occurrence pattern correlation: {results['cooccurrence_pattern_correlation']:.3f}")
         return self._agree(results)

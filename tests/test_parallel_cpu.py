@@ -166,7 +166,7 @@ def _val_worker(rank, world, port, q):
         ok &= abs(sharded_mean_offdiag(comm, k, local, cols) - V.mean_offdiag_correlation(synth.numpy(), cols)) < 1e-9
         ok &= abs(sharded_pearson(comm, k, local, 2, local, 7) - V.pearson(synth.numpy()[:, 2], synth.numpy()[:, 7])) < 1e-9
         ok &= comm.bcast_object(("x", rank)) == ("x", 0)
-        ok &= comm.sum(np.array([rank + 1, 10], dtype=np.int64)).tolist() == [3, 20]
+        ok &= comm.sum(np.array([rank + 1, 10], dtype=np.int64)).tolist() == [world * (world + 1) // 2, 10 * world]
         q.put((rank, bool(ok)))
     except Exception as e:                           # report instead of leaving the parent to time out
         q.put((rank, repr(e)))
@@ -175,20 +175,21 @@ def _val_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_validation_combination_gloo_world2():
+@pytest.mark.parametrize("world", [2, 3, 4])       # 3: every pair met once with weight 2; 4: the half-way round pairs both ends, weight 1
+def test_sharded_validation_combination_gloo(world):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_val_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_val_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
 
 
 def test_shardcomm_inactive_is_identity():
