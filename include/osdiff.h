@@ -95,7 +95,7 @@ int osd_set_stream(osd_handle *h, void *hip_stream);
  * pass through a private workspace -- the faster one from 65 536 rows on; 2 the LDS-resident chain, 64 patients per workgroup
  * with every activation in LDS, bit-identical, for architectures whose panels fit -- hidden_dims[0] = 256 = the last block's
  * width --, others fall back to 1; it runs at its full rate from 16 384 rows on; 0 auto: 1 from 65 536 rows on, 2 from 10 240 rows on), "dual_dgrad" / "train_ksplit" /
- * "train_input_splitk" / "persistent_bwd" (training-step experiments).  Auto sampler: the chain kernel when the batch has at least as many 128-row tiles as the device
+ * "train_input_splitk" (training-step experiments).  Auto sampler: the chain kernel when the batch has at least as many 128-row tiles as the device
  * holds resident workgroups (65 536 rows on an MI355X) or falls into the LDS-resident kernel's window (above), and the model is
  * in eval mode; else the per-layer kernels. */
 int osd_set_option(osd_handle *h, const char *name, int64_t value);

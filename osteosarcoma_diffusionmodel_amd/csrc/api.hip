@@ -11,7 +11,6 @@
 #include "kernels.h"
 #include "fwd.h"
 #include "launch.h"
-#include "bwd_host.h"
 #include "split.h"
 
 namespace osd {
@@ -360,7 +359,6 @@ int osd_create(const osd_config* cfg, osd_handle** out) {
   if (const char* e = getenv("OSD_GROUPED_WGRAD")) h->grouped_wgrad = atoi(e) != 0;      // A/B knobs, see osd_set_option
   if (const char* e = getenv("OSD_WGRAD_MID_FLUSH")) h->wgrad_mid_flush = atoi(e) != 0;
   if (const char* e = getenv("OSD_FUSED_GN_BWD")) h->fused_gn_bwd = atoi(e) != 0;
-  if (const char* e = getenv("OSD_PERSISTENT_BWD")) h->persistent_bwd = atoi(e) != 0;
   if (const char* e = getenv("OSD_TRAIN_INPUT_SPLITK")) h->train_input_splitk = atoi(e);
   if (const char* e = getenv("OSD_DUAL_DGRAD")) h->dual_dgrad = atoi(e) != 0;
   if (const char* e = getenv("OSD_TRAIN_KSPLIT")) h->train_ksplit = atoi(e) != 0;
@@ -403,7 +401,6 @@ int osd_destroy(osd_handle* h) {
   chain_free(h);
   split_free(h);
   wgrad_group_free(h);
-  bwd_persist_free(h);
   if (h->fork_ev) e = hipEventDestroy(h->fork_ev);
   (void)e;
   delete h;
@@ -494,16 +491,6 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
     h->grouped_wgrad = (int)value;
     return OSD_OK;
   }
-  if (!strcmp(name, "persistent_bwd")) {          // 1: dgrad chain + weight gradients of a backward pass as one persistent launch (default 0)
-    if (value < 0 || value > 1) { set_error("persistent_bwd must be 0 or 1"); return OSD_EINVAL; }
-    h->persistent_bwd = (int)value;
-    return OSD_OK;
-  }
-  if (!strcmp(name, "bwd_spin_budget")) {         // 100 MHz ticks a workgroup of the persistent backward launch may wait for work
-    if (value < 0) { set_error("bwd_spin_budget must be >= 0"); return OSD_EINVAL; }
-    h->bwd_spin_budget = (unsigned long long)value;
-    return OSD_OK;
-  }
   if (!strcmp(name, "fused_gn_bwd")) {
     if (value < 0 || value > 1) { set_error("fused_gn_bwd must be 0 or 1"); return OSD_EINVAL; }
     h->fused_gn_bwd = (int)value;
@@ -530,7 +517,7 @@ int osd_get_option(osd_handle* h, const char* name, int64_t* value) {
       {"chain_steps_per_launch", h->chain_steps_per_launch}, {"chain_stagger", h->chain_stagger},
       {"chain_spin_budget", (int64_t)h->chain_spin_budget}, {"chain_wall_budget_ms", h->chain_wall_budget_ms},
       {"grouped_wgrad", h->grouped_wgrad}, {"fused_gn_bwd", h->fused_gn_bwd}, {"wgrad_mid_flush", h->wgrad_mid_flush},
-      {"input_splitk", h->input_splitk}, {"train_streams", h->two_stream_bwd ? 2 : 1}, {"persistent_bwd", h->persistent_bwd}, {"bwd_spin_budget", (int64_t)h->bwd_spin_budget},
+      {"input_splitk", h->input_splitk}, {"train_streams", h->two_stream_bwd ? 2 : 1}, 
       // read-only counters
       {"precision", h->precision}, {"last_precision", h->last_precision}, {"split_supported", split_supported(h->arch) ? 1 : 0},
       {"chain_fallbacks", h->chain_fallbacks}, {"last_engine", h->last_engine},

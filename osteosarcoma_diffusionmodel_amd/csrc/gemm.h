@@ -210,9 +210,7 @@ struct StageNK {
 
 // ---- one output tile ---------------------------------------------------------------
 // Epi::apply<NFB,NPB,FAST>(acc, args, f_wave, p_wave, lane, F, P) consumes the wave's accumulators.
-// gemm_tile computes the BF x BP tile at (f0, p0) with all 256 threads of the workgroup; `smem` = T::LDS_BYTES of LDS.  Called by
-// gemm_kernel (one tile per workgroup) and by the persistent backward kernel (bwd_persist.h: a workgroup runs many tiles of
-// different GEMMs, with a barrier between two uses of `smem`).
+// gemm_tile computes the BF x BP tile at (f0, p0) with all 256 threads of the workgroup; `smem` = T::LDS_BYTES of LDS.
 // NG = 2 (gemm_kernel<..., 2>: 512 threads): two wave groups, each with its own staging buffers, reduce one half of the K tiles each;
 // group 1 hands its accumulators to group 0 through LDS and leaves, group 0 adds them and runs the epilogue (the two-wave-group
 // idea of gemm_glds.h for the register-staged kernel: the first dgrad of a training step is 256 tiles x 63 K tiles).

@@ -133,10 +133,6 @@ struct osd_handle {
   int fused_gn_bwd = 1;              // osd_set_option("fused_gn_bwd", 0|1): GroupNorm backward inside the dgrad epilogue (group widths 32 / 64)
   int wgrad_mid_flush = 0;           // osd_set_option("wgrad_mid_flush", 0|1): also launch the decoder-half weight gradients mid-pass
   int grouped_wgrad = 1;             // osd_set_option("grouped_wgrad", 0|1)
-  int persistent_bwd = 0;            // osd_set_option("persistent_bwd", 0|1): dgrad chain + weight gradients as one persistent launch (bwd_persist.h); parity-green but
-                                     // slower than the per-launch path on MI355X: off by default
-  unsigned long long bwd_spin_budget = 500000000ull;   // osd_set_option("bwd_spin_budget"): 100 MHz ticks a workgroup of that launch may wait
-  void* bwd_plan = nullptr;          // its cached work queues (bwd_persist.hip)
   // persistent reverse-chain kernel (chain.h / chain.hip)
   int sampler = 0;                   // osd_set_option("sampler"): 0 auto, 1 chain kernel whenever the architecture allows, 2 per-layer kernels
   int chain_grid = 0;                // 0 = min(row tiles, resident slots); > 0 caps the workgroup count (tests: force cross-workgroup hand-offs)

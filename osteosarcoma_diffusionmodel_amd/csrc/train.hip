@@ -8,13 +8,12 @@
 #include "kernels.h"
 #include "kernels_train.h"
 #include "fwd.h"
-#include "bwd_host.h"
 
 namespace osd {
 
 static int64_t align_up64(int64_t v) { return (v + 63) / 64 * 64; }
 static int t_pad(int T) { return (T + 31) / 32 * 32; }
-constexpr int WG_ROWS_ALIGN = 32;                          // the grouped weight-gradient items reduce whole 32-row K steps       // table rows padded to whole K steps of the grouped weight-gradient kernel
+
 
 struct TrainWs {
   FwdWs f;
@@ -163,7 +162,7 @@ static int side_stream(osd_handle* h, hipStream_t* out) {
 // activations a training-mode forward left in W.
 static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* x_t, int x_ld, const int* t_idx, const float* cond, int64_t n,
                          const float* d_out, bool train, const float* const* masks, uint64_t seed, uint32_t roff, float* const* grads,
-                         float* dx_t, void* const* events, bool try_persist = true) {
+                         float* dx_t, void* const* events) {
   const Arch& a = h->arch;
   const ParamMap& pm = a.pm;
   const int D = a.D;
@@ -211,20 +210,12 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   // has to see what the main stream produced: each fork costs the main stream a few microseconds, so only then)
   // b0..b2: bias gradients equal to the column sums of gz (the Linear's own bias and tensors that share it); they ride along
   // with the grouped launch, with the small kernel, or -- immediate GEMM path -- take a column-sum launch
-  // Persistent backward (bwd_persist.h): the dgrad chain of the trunk and the weight gradients fed by it are described to `pb`
-  // in program order and run as ONE launch (pb_dep >= -1: the tensor id of the gz operand, -1 = ready at launch); what the
-  // description cannot take (a width or alignment outside the kernel's tile code) sends the whole pass to the per-launch path.
-  BwdBuilder builder(n);
-  BwdBuilder* pb = nullptr;
-  bool pb_failed = false;
+  // (Round 3 also built the whole trunk backward as ONE persistent launch -- dgrad tiles and weight-gradient items as work units
+  // ordered by dependency counters.  Parity-green and slower, 800 vs 539 us: a wave streaming fp32 MFMAs starves the co-resident
+  // wave's VALU epilogue, so the dgrad chain stretched.  Removed in round 4; the stamps and the verdict are profiles/r03_bwd_persist.md.)
   auto wg = [&](const float* x, int ldx, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, int lddw,
-                float* b0 = nullptr, float* b1 = nullptr, float* b2 = nullptr, int pb_dep = -2) -> int {
+                float* b0 = nullptr, float* b1 = nullptr, float* b2 = nullptr) -> int {
     const WgPending wp{x, ldx, kin, gz, ldg, nout, rows, dw, lddw, {b0, b1, b2}};
-    static const int bwd_mode = [] { const char* e = getenv("OSD_BWD_MODE"); return e ? atoi(e) : 0; }();      // 1: dgrads only (experiments)
-    if (pb && pb_dep >= -1 && bwd_mode != 1) {
-      if (!pb->add_wgrad(wp, pb_dep)) pb_failed = true;
-      return OSD_OK;
-    }
     if (grp && kin >= 16 && wgrad_group_ok(wp)) { pend.push_back(wp); return OSD_OK; }
     const bool small = small_wgrad_ok(kin, nout, lddw);
     if (small && !events) {            // a 5 us kernel whose inputs are on the main stream: run it there (no fork, no event)
@@ -261,13 +252,6 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   bool fuse = h->fused_gn_bwd != 0;
   fuse = fuse && grp != nullptr;       // the fused path's bias / affine gradients ride with the grouped launches
   for (const LayerDesc& l : a.layers) fuse = fuse && dgrad_gnbwd_supported(l.gw);
-  if (try_persist && fuse && h->persistent_bwd && !events && !dx_t && n >= 64 && n % WG_ROWS_ALIGN == 0) pb = &builder;
-  std::vector<int> t_z1, t_z2, t_skip;      // tensor ids of the persistent plan: dL/dz of both halves of a block, the skip share of an encoder output
-  int t_h0 = -1;
-  if (pb) {
-    for (int b = 0; b < a.n_blocks; ++b) { t_z1.push_back(pb->new_tensor()); t_z2.push_back(pb->new_tensor()); t_skip.push_back(pb->new_tensor()); }
-    t_h0 = pb->new_tensor();
-  }
   const float keep_scale = (float)(1.0 / (1.0 - (double)h->cfg.dropout_p));
   std::vector<GnColItem> cols;
   // d gamma / d beta of the layers whose backward ran in a dgrad epilogue: memory-bound leaves, one launch per call.  They
@@ -321,8 +305,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   // dgrad whose epilogue is the GroupNorm+SiLU(+dropout) backward of `ln` (z / stats of that layer): writes dL/dz and dL/dy
   auto dgrad_fused = [&](const float* w, int ldw, int kin, const float* gz_next, int ldg, int nout, const LayerDesc& ln, const float* z,
                          const float* stats, float* gz_out, float* gy_buf, bool accumulate, bool with_drop, int blk,
-                         int dep0 = -1, int dep1 = -1, int sig = -1, const float* w_skip = nullptr, int kin_skip = 0, float* out_skip = nullptr,
-                         bool* skip_done = nullptr) -> int {
+                         const float* w_skip = nullptr, int kin_skip = 0, float* out_skip = nullptr, bool* skip_done = nullptr) -> int {
     GemmArgs g{};
     g.A = w; g.lda = ldw; g.B0 = gz_next; g.ldb0 = ldg; g.K0 = nout; g.F = kin; g.P = (int)n; g.K = nout;
     g.ksplit = h->train_ksplit != 0;       // launch.h: two wave groups where a launch has ~one tile per CU and >= 32 K tiles (the first dgrad)
@@ -332,9 +315,7 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     e.drop_mode = with_drop ? (masks ? 1 : 2) : 0;
     e.mask = (with_drop && masks) ? masks[blk] : nullptr; e.ldm = kin; e.keep_scale = keep_scale; e.p_drop = h->cfg.dropout_p;
     e.seed = seed; e.row_offset = roff; e.step = 0; e.tag = TAG_DROPOUT + (uint32_t)blk;
-    if (pb) {
-      if (!pb->add_dgrad({ln.gw, with_drop ? 1 : 0, g, e, dep0, dep1, sig})) pb_failed = true;
-    } else {
+    {
       bool launched = false;
       if (w_skip && h->dual_dgrad) {
         // the skip connection's share of the same gz (plain dX = gz W_skip) rides in the same launch
@@ -350,23 +331,17 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     cols.push_back({gy_buf, kin, z, kin, stats, kin, ln.gw, n, grads[ln.gamma], grads[ln.beta]});
     return OSD_OK;
   };
-  // plain dgrad dX = gz W (no epilogue): a launch, or tiles of the persistent plan
-  auto dgrad_plain = [&](const float* w, int ldw, int kin, const float* gz, int ldg, int nout, float* dx, int lddx, int dep0, int sig) -> int {
-    if (!pb) { OSD_HIP(dgrad(s, w, ldw, kin, gz, ldg, nout, n, dx, lddx, false)); return OSD_OK; }
-    GemmArgs g{};
-    g.A = w; g.lda = ldw; g.B0 = gz; g.ldb0 = ldg; g.K0 = nout; g.F = kin; g.P = (int)n; g.K = nout;
-    GnBwdEpi e{};
-    e.gz = dx; e.ldg = lddx;
-    if (!pb->add_dgrad({0, 0, g, e, dep0, -1, sig})) pb_failed = true;
+  // plain dgrad dX = gz W (no epilogue)
+  auto dgrad_plain = [&](const float* w, int ldw, int kin, const float* gz, int ldg, int nout, float* dx, int lddx) -> int {
+    OSD_HIP(dgrad(s, w, ldw, kin, gz, ldg, nout, n, dx, lddx, false));
     return OSD_OK;
   };
   // output_proj
-  OSD_TRY(wg(W.f.out[last], Hl, Hl, d_out, D, D, n, grads[pm.out_w], Hl, grads[pm.out_b], nullptr, nullptr, -1));
+  OSD_TRY(wg(W.f.out[last], Hl, Hl, d_out, D, D, n, grads[pm.out_w], Hl, grads[pm.out_b]));
   OSD_TRY(record());
   if (fuse) {
     const LayerDesc& lz = a.layers[2 * last + 1];
-    OSD_TRY(dgrad_fused(h->params[pm.out_w], Hl, Hl, d_out, D, D, lz, W.f.z2[last], W.f.st2[last], W.g_z2[last], W.g_out[last], false, false, last,
-                        -1, -1, pb ? t_z2[last] : -1));
+    OSD_TRY(dgrad_fused(h->params[pm.out_w], Hl, Hl, d_out, D, D, lz, W.f.z2[last], W.f.st2[last], W.g_z2[last], W.g_out[last], false, false, last));
   } else {
     OSD_HIP(dgrad(s, h->params[pm.out_w], Hl, Hl, d_out, D, D, n, W.g_out[last], Hl, false));
   }
@@ -383,24 +358,22 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     const bool acc = (b >= 1) && (b - 1 < a.n_enc);      // encoder outputs already hold their skip gradient
     if (fuse) {
       // dL/dz of the second half is in g_z2[b] (left by the dgrad above it); bias gradients ride with the weight gradients
-      const int tz1 = pb ? t_z1[b] : -2, tz2 = pb ? t_z2[b] : -2;      // -2: not a persistent pass
       bool skip_done = false;
-      OSD_TRY(wg(W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C, grads[l2.b], nullptr, nullptr, tz2));
-      OSD_TRY(dgrad_fused(h->params[l2.w], C, C, W.g_z2[b], C, C, l1, W.f.z1[b], W.f.st1[b], W.g_z1[b], W.g_mid[b], false, drop, b, tz2, -1, tz1));
-      OSD_TRY(wg(xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt, grads[l1.b], nullptr, nullptr, tz1));
-      if (l1.K2 > 0) OSD_TRY(wg(W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt, nullptr, nullptr, nullptr, tz1));
+      OSD_TRY(wg(W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C, grads[l2.b]));
+      OSD_TRY(dgrad_fused(h->params[l2.w], C, C, W.g_z2[b], C, C, l1, W.f.z1[b], W.f.st1[b], W.g_z1[b], W.g_mid[b], false, drop, b));
+      OSD_TRY(wg(xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt, grads[l1.b]));
+      if (l1.K2 > 0) OSD_TRY(wg(W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt));
       OSD_TRY(record());
-      if (!pb && b == a.n_enc && (h->wgrad_mid_flush || events)) OSD_TRY(flush_all(true));
+      if (b == a.n_enc && (h->wgrad_mid_flush || events)) OSD_TRY(flush_all(true));
       if (b == 0) {
-        OSD_TRY(dgrad_plain(h->params[l1.w], Kt, l1.K1, W.g_z1[b], C, C, gdst, l1.K1, tz1, t_h0));
+        OSD_TRY(dgrad_plain(h->params[l1.w], Kt, l1.K1, W.g_z1[b], C, C, gdst, l1.K1));
       } else {
         const LayerDesc& lp = a.layers[2 * (b - 1) + 1];      // the layer that produced this block's main input
         // an encoder output already holds its skip gradient (written by the decoder block that popped it): second dependency
         OSD_TRY(dgrad_fused(h->params[l1.w], Kt, l1.K1, W.g_z1[b], C, C, lp, W.f.z2[b - 1], W.f.st2[b - 1], W.g_z2[b - 1], W.g_out[b - 1], acc,
-                            false, b - 1, tz1, (pb && acc) ? t_skip[b - 1] : -1, pb ? t_z2[b - 1] : -1,
-                            l1.K2 > 0 ? h->params[l1.w] + l1.K1 : nullptr, l1.K2, l1.K2 > 0 ? W.g_out[skip_block] : nullptr, &skip_done));
+                            false, b - 1, l1.K2 > 0 ? h->params[l1.w] + l1.K1 : nullptr, l1.K2, l1.K2 > 0 ? W.g_out[skip_block] : nullptr, &skip_done));
       }
-      if (l1.K2 > 0 && !skip_done) OSD_TRY(dgrad_plain(h->params[l1.w] + l1.K1, Kt, l1.K2, W.g_z1[b], C, C, W.g_out[skip_block], l1.K2, tz1, pb ? t_skip[skip_block] : -1));
+      if (l1.K2 > 0 && !skip_done) OSD_TRY(dgrad_plain(h->params[l1.w] + l1.K1, Kt, l1.K2, W.g_z1[b], C, C, W.g_out[skip_block], l1.K2));
       continue;
     }
     // second half: GroupNorm+SiLU backward, wgrad, dgrad
@@ -430,24 +403,13 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   }
   // input_proj, time_proj, cond_proj, ConditionalEmbedding  (h0 = x W^T + b + t_emb[t] + c_proj)
   // h0 = x W^T + b_in + (t_emb W_t^T + b_t)[t] + (c W_c^T + b_c): the three biases share one gradient, the column sums of g_h0
-  if (pb) {
-    OSD_TRY(wg(x_t, x_ld, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D, grads[pm.in_b], grads[pm.cp_b], grads[pm.tp_b], t_h0));
-    OSD_TRY(wg(W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64, nullptr, nullptr, nullptr, t_h0));
-    if (pb_failed) return backward_from(h, s, W, x_t, x_ld, t_idx, cond, n, d_out, train, masks, seed, roff, grads, dx_t, events, false);
-    OSD_TRY(pb->launch(h, s, W.slabs, W.slab_floats, seed, roff));
-    pb = nullptr;                       // the rest of the pass (the conditioning branch) runs launch by launch
-  }
   // (Tried: the conditioning branch's backward -- five dependent launches of 5-13 us -- and the affine-gradient column sums on the
   // side stream BESIDE the grouped weight-gradient launch instead of in front of it.  The grouped launch's older waves starve
   // them: k_gn_colsums took 202 us instead of 44 and the side chain ended after the main one -- 1042 vs 988 us per step.  Dropped.)
   if (s2 != s && !cols.empty()) { OSD_TRY(fork()); OSD_TRY(side_leaves(s2)); }      // every GroupNorm layer's gy / z is final
   if (dx_t) OSD_HIP(dgrad(s, h->params[pm.in_w], D, D, W.g_h0, a.H0, a.H0, n, dx_t, D, false));
-  if (!builder.empty()) {
-    // input_proj / cond_proj weight gradients went with the persistent launch
-  } else {
-    OSD_TRY(wg(x_t, x_ld, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D, grads[pm.in_b], grads[pm.cp_b], grads[pm.tp_b]));
-    OSD_TRY(wg(W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64));
-  }
+  OSD_TRY(wg(x_t, x_ld, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D, grads[pm.in_b], grads[pm.cp_b], grads[pm.tp_b]));
+  OSD_TRY(wg(W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64));
   OSD_HIP(launch_scatter_rows(s, W.g_h0, t_idx, n, a.H0, W.g_temb));
   OSD_HIP(dgrad(s, h->params[pm.cp_w], 64, 64, W.g_h0, a.H0, a.H0, n, W.g_ce2, 64, false));
   // both tables carry zero rows up to a multiple of 32 (whole K steps of the grouped kernel): they add nothing

@@ -255,7 +255,6 @@ class BiologyAwareDiffusionModel(nn.Module):
         self.precision: Optional[str] = None
         self.last_precision: Optional[str] = None         # what the most recent predict_noise / p_sample / sample computed in
         self.train_streams: Optional[int] = None      # 1 = whole backward on one stream, 2 (library default) = weight gradients on a side stream
-        self.persistent_bwd: Optional[int] = None     # 1 = dgrad chain + weight gradients as one persistent launch (csrc/bwd_persist.h; library default 0)
         # optional constraint losses (set_constraints); None = the reference's eps-MSE only
         self._constraints = None
         self._constraints_version = 0
@@ -347,8 +346,6 @@ class BiologyAwareDiffusionModel(nn.Module):
             L.check(L.lib().osd_set_option(eng.handle, b"n_streams", int(self.sample_streams)))
         if self.train_streams:
             L.check(L.lib().osd_set_option(eng.handle, b"train_streams", int(self.train_streams)))
-        if self.persistent_bwd is not None:
-            L.check(L.lib().osd_set_option(eng.handle, b"persistent_bwd", int(self.persistent_bwd)))
         try:
             mode = {"auto": 0, "chain": 1, "graph": 2, "layers": 2}[self.sampler]
         except KeyError:

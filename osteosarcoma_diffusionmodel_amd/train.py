@@ -597,7 +597,7 @@ class Trainer:
 
     def _option_state(self):
         m = self.model
-        return tuple(getattr(m, k, None) for k in ("train_streams", "persistent_bwd", "sampler", "input_splitk"))
+        return tuple(getattr(m, k, None) for k in ("train_streams", "sampler", "input_splitk", "precision"))
 
     def _bcast(self, t: torch.Tensor):
         """Broadcast from rank 0 in place (staged through the host when the backend is gloo)."""
@@ -618,7 +618,7 @@ class Trainer:
             raise RuntimeError("model parameters were re-allocated after Trainer construction (e.g. model.to()); rebuild the Trainer")
         if self._engine is not None and (self._engine.constraints_version != self.model._constraints_version or
                                          self._opts != self._option_state()):
-            # set_constraints() or a tunable (train_streams, persistent_bwd, ...) changed after construction: let the model's own
+            # set_constraints() or a tunable (train_streams, ...) changed after construction: let the model's own
             # engine lookup re-apply them once (it also re-derives the tables), then keep using the fast path
             self._engine = self.model._engine()
             self._opts = self._option_state()
