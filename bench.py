@@ -600,17 +600,25 @@ def roofline_leg(model, args, cond, offset, dev, engine_used, sample_ms, step_fn
     from osteosarcoma_diffusionmodel_amd import _lib as L
     eng = model._engine()
     T = CONF["model"]["diffusion"]["num_steps"]
-    traffic_files = [ROOT / "profiles" / n for n in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")]
+    traffic_files = [ROOT / "profiles" / n for n in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")]
+    import hashlib
+    lib_sha = hashlib.sha256(Path(os.environ.get("OSDIFF_LIB", L.LIB_PATH)).read_bytes()).hexdigest()
 
     def traffic_for(key, scale_units):
+        """HBM-side bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE) -- quoted only when the file was collected
+        on THIS build of the library (its recorded sha256 equals the loaded .so's); a stale file gives traffic: null, not a figure."""
         for tj in traffic_files:
             if tj.exists():
                 t = json.loads(tj.read_text())
                 ent = t.get("traffic_bytes_per_launch", {}).get(key)
-                if ent is not None:
-                    per_unit = ent / t["units_per_launch"][key] if "units_per_launch" in t else ent / t["rows_per_launch"]
-                    return round(per_unit * scale_units), (f"profiles/{tj.name}: rocprofv3 --pmc passes of an EARLIER run of this kernel "
-                                                           f"(2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), scaled by work; not measured in this run")
+                if ent is None:
+                    continue
+                if t.get("library_sha256") != lib_sha:
+                    return None, (f"profiles/{tj.name} was collected on another build of libosdiff.so (sha256 {str(t.get('library_sha256'))[:12]}... "
+                                  f"vs loaded {lib_sha[:12]}...): no traffic figure quoted for this run; tools/round_pmc.sh regenerates it")
+                per_unit = ent / t["units_per_launch"][key] if "units_per_launch" in t else ent / t["rows_per_launch"]
+                return round(per_unit * scale_units), (f"profiles/{tj.name}: rocprofv3 --pmc passes of THIS build of the library (sha256 match) in a separate run "
+                                                       f"(2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), scaled by work; not measured inside the timed region")
         return None, None
 
     # ---- per-layer engine: per-launch table (also reported when the chain engine is the default: it is the fallback path) ----

@@ -119,8 +119,11 @@ int osd_set_schedule(osd_handle *h, const float *sqrt_ac, const float *sqrt_1m_a
 
 /* nn.Module parameters (models/diffusion.py:283-295): n == osd_num_params() device
  * pointers in named_parameters() order.  Borrowed; derived tables (time_proj applied
- * to the time-embedding table) are recomputed on the handle's stream.  Call again
- * after any in-place parameter update. */
+ * to the time-embedding table, packed / plane copies of weights) are recomputed on the
+ * handle's stream.  Call again after any in-place parameter update the library cannot
+ * see (an update through osd_clip_adamw_step on this handle, or a training call that
+ * skipped a repack, is seen: the next forward / sampling entry point refreshes the
+ * derived copies itself). */
 int osd_load_weights(osd_handle *h, const float *const *params, int n);
 
 /* DiffusionUNet.forward in eval/train mode on n rows (models/diffusion.py:210-256)

@@ -18,8 +18,8 @@ def _respect_cpu_quota():
     index gather of 57 000 rows -- then wakes the whole OpenMP team, the idle workers spin at the region's barrier, the CFS quota
     of the 100 ms period is gone, and EVERY thread of the process, HIP's runtime threads included, is frozen until the next
     period: 60-90 ms GPU stalls on a 100 ms grid (tools/throttle_check.sh: nr_throttled 2 -> 20 during 170 training steps;
-    none with a capped pool, and the epoch loop went from 2.0 to 1.03 ms/step).  Cap the pool at the quota once, at import;
-    OSD_KEEP_TORCH_THREADS=1 leaves torch's setting alone."""
+    none with a capped pool, and the epoch loop went from 2.0 to 1.03 ms/step).  Cap the pool at the quota once, at import, and
+    log the change once (logger `osteosarcoma_diffusionmodel_amd`, WARNING); OSD_KEEP_TORCH_THREADS=1 leaves torch's setting alone."""
     import os
     if os.environ.get("OSD_KEEP_TORCH_THREADS") == "1":
         return
@@ -31,8 +31,14 @@ def _respect_cpu_quota():
     except (OSError, ValueError):
         return
     import torch
-    if torch.get_num_threads() > cores:
+    before = torch.get_num_threads()
+    if before > cores:
         torch.set_num_threads(cores)
+        # a drop-in package changing a process-wide setting of its host says so, once (the import runs once per process)
+        import logging
+        logging.getLogger(__name__).warning(
+            "torch intra-op threads capped %d -> %d (the cgroup's cpu.max quota; OSD_KEEP_TORCH_THREADS=1 leaves torch's setting alone)",
+            before, cores)
 
 
 _respect_cpu_quota()

@@ -176,7 +176,18 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
       else if (e != hipErrorInvalidValue) OSD_HIP(e);
       else (void)hipGetLastError();
     }
-    if (!done) OSD_HIP(launch_input(s, g, ea, true));
+    if (!done) {
+      hipError_t e = launch_input(s, g, ea, true);
+      if (e == hipErrorInvalidValue && in.a_unpacked) {
+        // the clamped-weight path needs 16-byte aligned parameter pointers (launch.h: glds_ok / fast_ok), which the caller of
+        // osd_load_weights does not owe us: pack the padded copy after all and read that (x already has zero pad columns)
+        (void)hipGetLastError();
+        OSD_HIP(launch_copy2d(s, h->params[pm.in_w], a.D, h->w_in_packed, h->w_in_ld, a.H0, a.D));
+        g.A = h->w_in_packed; g.lda = h->w_in_ld; g.a_kmax = 0;
+        e = launch_input(s, g, ea, true);
+      }
+      OSD_HIP(e);
+    }
     OSD_TRY(prof_mark(h, s));
   }
   const float* cur = ws.h0;
@@ -234,7 +245,11 @@ int refresh_derived(osd_handle* h, hipStream_t s, bool pack_in_w) {
   OSD_HIP(launch_linear(s, g, true, true, h->params[a.pm.tp_b], h->d_temb, a.H0, false, false));
   h->panel_wpk_valid = false;           // the LDS-resident chain repacks its fragment-ordered copies before its next run
   h->split_valid = false;               // ... and the bf16x3 engine its weight planes
-  if (!pack_in_w) return OSD_OK;        // a training step that reads input_proj.weight directly (the next osd_load_weights packs it)
+  if (!pack_in_w) {                     // a training step that reads input_proj.weight directly: the packed copies go stale and are
+    h->w_packed_stale = true;           // refreshed by the next entry point that reads them (ensure_packed) or osd_load_weights
+    return OSD_OK;
+  }
+  h->w_packed_stale = false;
   OSD_HIP(launch_copy2d(s, h->params[a.pm.in_w], a.D, h->w_in_packed, h->w_in_ld, a.H0, a.D));   // pad columns stay zero
   if (h->w_out_packed) {                       // D % 4 != 0: rows [D, Dp) stay zero
     const size_t hl = (size_t)a.block_out[a.n_blocks - 1];
@@ -242,6 +257,13 @@ int refresh_derived(osd_handle* h, hipStream_t s, bool pack_in_w) {
     OSD_HIP(hipMemcpyAsync(h->b_out_packed, h->params[a.pm.out_b], (size_t)a.D * 4, hipMemcpyDeviceToDevice, s));
   }
   return OSD_OK;
+}
+
+// The packed input_proj / output_proj copies follow the parameters lazily: a training step that does not read them skips the
+// repack (refresh_derived above), and a C-ABI caller may sample right after such a step without another osd_load_weights.
+int ensure_packed(osd_handle* h, hipStream_t s) {
+  if (!h->w_packed_stale) return OSD_OK;
+  return refresh_derived(h, s, true);
 }
 
 // padded: the epilogue works on the padded chain state (Dp columns; the packed weight has zero rows for the pad columns)
@@ -581,6 +603,7 @@ int osd_denoiser_forward(osd_handle* h, const float* x, const int32_t* t_index, 
   if (n == 0) return OSD_OK;
   OSD_HIP(hipSetDevice(h->cfg.device));
   hipStream_t s = h->stream;
+  OSD_TRY(ensure_packed(h, s));
   const int* t_idx = nullptr;
   OSD_TRY(sanitize_t(h, s, t_index, n, &t_idx));
   if (h->precision == 1 && !(flags & OSD_F_TRAIN_MODE) && !masks) {      // eval mode on the bf16 matrix pipe; dropout stays fp32
@@ -628,6 +651,7 @@ int osd_p_sample_step(osd_handle* h, const float* x_t, int32_t t, const float* c
   OSD_TRY(check_row_offset(row_offset, n));
   if (n == 0) return OSD_OK;
   OSD_HIP(hipSetDevice(h->cfg.device));
+  OSD_TRY(ensure_packed(h, h->stream));
   if (h->precision == 1 && !((flags & OSD_F_TRAIN_MODE) && h->cfg.dropout_p > 0.f)) {
     OSD_TRY(split_p_sample_step(h, x_t, t, cond, z, n, seed, row_offset, x_out));
     if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(h->stream));
@@ -751,6 +775,7 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
   if (n == 0) return OSD_OK;
   OSD_HIP(hipSetDevice(h->cfg.device));
   OSD_TRY(chain_check_status(h));            // a previous chain-kernel run that gave up is reported here at the latest
+  OSD_TRY(ensure_packed(h, h->stream));
   // bf16x3 split precision: eval-mode chains on the per-layer launches of split.hip (dropout inside the chain stays fp32)
   const bool split = h->precision == 1 && !((flags & OSD_F_TRAIN_MODE) && h->cfg.dropout_p > 0.f);
   h->last_precision = split ? 1 : 0;
@@ -843,6 +868,7 @@ int osd_profile_step(osd_handle* h, const float* cond, int64_t n, int reps, floa
   if (max_entries < n_launch) { set_error("need room for %d entries", n_launch); return OSD_EINVAL; }
   OSD_HIP(hipSetDevice(h->cfg.device));
   hipStream_t s = h->stream;
+  OSD_TRY(ensure_packed(h, s));
   FwdWs ws;
   const int64_t fwd = carve_fwd(a, nullptr, n, false, &ws);
   const int64_t need = fwd + align_up(n * a.D, 64);

@@ -26,6 +26,7 @@ int64_t carve_fwd(const Arch& a, float* base, int64_t n, bool train, FwdWs* ws);
 int run_cond(osd_handle* h, hipStream_t s, const float* cond, int64_t n, const FwdWs& ws);
 int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in);
 int refresh_derived(osd_handle* h, hipStream_t s, bool pack_in_w = true);
+int ensure_packed(osd_handle* h, hipStream_t s);
 GemmArgs output_proj_args(osd_handle* h, const FwdWs& ws, int64_t n, bool padded = false);
 int check_ready(osd_handle* h);
 int check_rows(int64_t n);

@@ -93,6 +93,7 @@ struct osd_handle {
   bool have_schedule = false, have_weights = false;
   float* w_in_packed = nullptr;      // input_proj.weight zero-padded to [H0][roundup(D,32)] for the LDS-DMA kernel
   int w_in_ld = 0;
+  bool w_packed_stale = false;      // a training step skipped the repack of w_in_packed / w_out_packed: refreshed lazily (api.hip: ensure_packed)
   // D % 4 != 0 (e.g. the reference's real dims 62 + 5054 + 26 = 5142): the reverse chain keeps its state in an internal buffer
   // whose rows are padded to Dp = roundup(D, 4) floats, so that every operand is 16-byte aligned and the LDS-DMA / FAST tile code
   // and the chain kernel apply; the pad columns carry finite values that only ever meet zero weights

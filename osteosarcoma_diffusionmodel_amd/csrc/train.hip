@@ -667,6 +667,9 @@ int osd_clip_adamw_step(osd_handle* h, float* param, float* grad, float* exp_avg
   if (numel <= 0 || step < 1) { set_error("numel and step must be positive"); return OSD_EINVAL; }
   OSD_HIP(hipSetDevice(h->cfg.device));
   if (!h->normsq_dev) OSD_HIP(hipMalloc((void**)&h->normsq_dev, 256 * sizeof(double)));
+  // the handle's own optimizer is about to change parameters it may hold derived copies of (t_emb table, packed input_proj /
+  // output_proj, chain and bf16x3 weight copies): the next forward / sampling entry point refreshes them (api.hip: ensure_packed)
+  h->w_packed_stale = true;
   return clip_adamw(h->stream, h->normsq_dev, param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, max_norm, step,
                     grad_norm_out);
 }

@@ -505,6 +505,13 @@ class BiologyAwareDiffusionModel(nn.Module):
             # the chain kernel's bounded waits report through a status word: the synchronous call reads it and, should the
             # chain have given up, re-runs it on the per-layer kernels (same bits) -- sample() cannot fail, as the reference's
             flags |= L.OSD_F_SYNC
+
+        def counter(name):
+            v = C.c_int64(0)
+            L.check(L.lib().osd_get_option(eng.handle, name, C.byref(v)))
+            return int(v.value)
+
+        gave_up_before = counter(b"chain_fallbacks")
         L.check(L.lib().osd_sample_chain(eng.handle, L.ptr(conditions), n, L.ptr(xT), L.ptr(zs), seed, int(row_offset),
                                          L.ptr(out), L.ptr(mask), flags))
         used = L.lib().osd_sample_engine(eng.handle, -1, 0)      # the engine that produced the result
@@ -512,13 +519,13 @@ class BiologyAwareDiffusionModel(nn.Module):
             L.check(used)
         self.last_sampler = "chain" if used == 1 else "graph"
         self._note_precision(eng)
+        # a chain kernel ran iff the result is its own or it gave up and was re-run (the counter moved); a call the library
+        # demoted up front (injected draws at D % 4 != 0 keep the guarded per-layer kernels) launched none and warns about nothing
+        gave_up = counter(b"chain_fallbacks") > gave_up_before
         self.last_chain_variant = None
-        if engine == 1:                      # which chain kernel ran (also set when its result was discarded for the re-run)
-            import ctypes as C
-            v = C.c_int64(0)
-            L.check(L.lib().osd_get_option(eng.handle, b"last_chain_variant", C.byref(v)))
-            self.last_chain_variant = {1: "workspace", 2: "panel"}.get(int(v.value))
-        if engine == 1 and used != 1:
+        if used == 1 or gave_up:
+            self.last_chain_variant = {1: "workspace", 2: "panel"}.get(counter(b"last_chain_variant"))
+        if gave_up:
             import warnings
             warnings.warn(L.last_error() or "the reverse-chain kernel gave up; the chain was re-run on the per-layer kernels")
         if return_mutation_mask:

@@ -385,7 +385,11 @@ class ResidentSplit:
             if gen is None:                       # RandomSampler.__iter__: a fresh generator seeded from the default one
                 gen = torch.Generator()
                 gen.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
-            return torch.randperm(n, generator=gen)
+            order = torch.randperm(n, generator=gen)
+            # RandomSampler.__iter__ draws a SECOND permutation for its (here empty) tail, `randperm(n)[:num_samples % n]`: with a
+            # caller-supplied generator that draw advances the state the next epoch starts from, so it is made here too
+            torch.randperm(n, generator=gen)
+            return order
         return torch.as_tensor(list(smp), dtype=torch.int64)
 
     def epoch_indices(self):

@@ -47,6 +47,23 @@ def test_order_matches_the_dataloader_shuffled_and_sequential():
     assert sorted(torch.cat(got_v).tolist()) == sorted(val_ds.indices)   # every validation row exactly once, last batch short
 
 
+def test_order_matches_a_loader_with_its_own_generator_over_epochs():
+    """DataLoader(shuffle=True, generator=g): RandomSampler draws TWO permutations per epoch from g (the pass and its empty tail),
+    so epoch 2 only matches if the resident path makes the second draw as well (round-3 advisor finding)."""
+    base = _dataset(90)
+    want_loader = DataLoader(base, batch_size=16, shuffle=True, num_workers=0, drop_last=True, generator=torch.Generator().manual_seed(5))
+    got_loader = DataLoader(base, batch_size=16, shuffle=True, num_workers=0, drop_last=True, generator=torch.Generator().manual_seed(5))
+    rs = ResidentSplit.build(got_loader, "cpu", {}, budget_bytes=1 << 30)
+    assert rs is not None
+    for epoch in range(4):
+        want = _visited(want_loader)
+        got = rs.epoch_indices()
+        assert len(got) == len(want) == 5
+        for a, b in zip(got, want):
+            assert torch.equal(rs.base[0][a][:, 0].to(torch.int64), b), f"epoch {epoch}"
+        assert torch.equal(want_loader.generator.get_state(), got_loader.generator.get_state())
+
+
 def test_order_matches_a_distributed_sampler_shard():
     base = _dataset(200)
     train_ds, _ = torch.utils.data.random_split(base, [160, 40], generator=torch.Generator().manual_seed(1))

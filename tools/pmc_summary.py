@@ -11,6 +11,12 @@ def klass(name):
     if "panel_chain_kernel" in name: return "panel_chain_kernel"
     if "chain_kernel" in name: return "chain_kernel"
     if "wgrad_group_kernel" in name: return "wgrad_group_kernel"
+    if "gemm_bf3_kernel" in name:
+        if "EpiB3Gn<32" in name: return "bf16x3 GnSilu<32>"
+        if "EpiB3Gn<64" in name: return "bf16x3 GnSilu<64>"
+        if "EpiB3Input" in name: return "bf16x3 Input"
+        if "EpiB3Post" in name: return "bf16x3 Posterior"
+        return None
     if "gemm_glds_kernel" not in name or "128, 128, 64, 64" not in name: return None
     if "EpiGnSilu<32" in name: return "GnSilu<32> glds"
     if "EpiGnSilu<64" in name: return "GnSilu<64> glds"
@@ -47,6 +53,13 @@ for k in sorted(vals):
     print(f"| {k} | {n} | {sum(dur[k]) / max(len(dur[k]), 1) / 1e6:.3f} | {busy:.3f} | {avg(k, 'SQ_LDS_BANK_CONFLICT'):.0f} | {fetch:.0f} | {write:.0f} | "
           f"{tr / 1e6:.1f} | {hit / (hit + miss):.3f} | {avg(k, 'SQ_INSTS_VALU'):.0f} |")
 units = {k: (chain_units if k in ("chain_kernel", "panel_chain_kernel") else 32768.0) for k in traffic}
+# the library these counters were collected on: bench.py only quotes a traffic figure for the build it is running (sha256 of the .so)
+import hashlib, os
+from pathlib import Path
+lib_path = Path(os.environ.get("OSDIFF_LIB", Path(__file__).resolve().parent.parent / "osteosarcoma_diffusionmodel_amd" / "lib" / "libosdiff.so"))
+lib_sha = hashlib.sha256(lib_path.read_bytes()).hexdigest() if lib_path.exists() else None
+tj = {"rows_per_launch": 32768, "units_per_launch": units, "traffic_bytes_per_launch": traffic,
+      "unit_of": {"chain_kernel": "patient-steps", "default": "rows"}, "source": f"profiles/{tag}_pmc.md", "library_sha256": lib_sha}
 print()
-print("traffic_json:", json.dumps({"rows_per_launch": 32768, "units_per_launch": units, "traffic_bytes_per_launch": traffic,
-                                   "unit_of": {"chain_kernel": "patient-steps", "default": "rows"}, "source": f"profiles/{tag}_pmc.md"}))
+print("traffic_json:", json.dumps(tj))
+Path(root, f"{tag}_traffic.json").write_text(json.dumps(tj, indent=1))

@@ -13,4 +13,4 @@ print('value', d['value'], 'roof', d['roofline']['frac'], 'train', d['train']['m
 print('refw', [(r['D'], r['patients_per_scenario'], r['patients_per_s']) for r in d['reference_workload']['runs']])
 print('validate', [(s['mmd']['tflops'], s['validate_all']['s']) for s in d['validate']['scenarios']])
 PY
-bash tools/train_pmc.sh r03 > gpurun_out/rc/train_pmc.log 2>&1; tail -3 gpurun_out/rc/train_pmc.log
+bash tools/train_pmc.sh r04 > gpurun_out/rc/train_pmc.log 2>&1; tail -3 gpurun_out/rc/train_pmc.log
