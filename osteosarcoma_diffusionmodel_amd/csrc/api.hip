@@ -208,6 +208,16 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
     ga.out = ws.mid[b]; ga.ldo = l1.N;
     ga.z_out = in.save ? ws.z1[b] : nullptr; ga.ldz = l1.N; ga.stats = in.save ? ws.st1[b] : nullptr;
     const bool drop = in.train && h->cfg.dropout_p > 0.f;
+    // small batches: a deep layer is a few dozen tiles of 16-32 sequential K steps -- K in slices over workgroups + a reduce kernel
+    auto gn_split = [&](const GemmArgs& gg, const GnArgs& aa) -> int {      // 1 = launched, 0 = not applicable, < 0 = error
+      if (in.gn_slices < 2 || !in.gn_slabs || in.save || gg.K < 512) return 0;
+      const hipError_t e = launch_gn_silu_splitk(s, gg, aa, in.gn_slabs, in.gn_slices);
+      if (e == hipSuccess) return 1;
+      (void)hipGetLastError();
+      if (e == hipErrorInvalidValue) return 0;
+      set_error("launch_gn_silu_splitk failed: %s", hipGetErrorString(e));
+      return OSD_EHIP;
+    };
     if (drop) {
       ga.drop_mode = in.masks ? 1 : 2;
       ga.mask = in.masks ? in.masks[b] : nullptr; ga.ldm = l1.N;
@@ -216,7 +226,9 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
       ga.step_dev = in.drop_step_dev;
       OSD_HIP(launch_gn_silu_drop(s, g, l1.gw, ga));
     } else {
-      OSD_HIP(launch_gn_silu(s, g, l1.gw, ga));
+      const int sp = gn_split(g, ga);
+      if (sp < 0) return sp;
+      if (!sp) OSD_HIP(launch_gn_silu(s, g, l1.gw, ga));
     }
     OSD_TRY(prof_mark(h, s));
     GemmArgs g2{};
@@ -226,7 +238,11 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
     gb.bias = h->params[l2.b]; gb.gamma = h->params[l2.gamma]; gb.beta = h->params[l2.beta];
     gb.out = ws.out[b]; gb.ldo = l2.N;
     gb.z_out = in.save ? ws.z2[b] : nullptr; gb.ldz = l2.N; gb.stats = in.save ? ws.st2[b] : nullptr;
-    OSD_HIP(launch_gn_silu(s, g2, l2.gw, gb));
+    {
+      const int sp = gn_split(g2, gb);
+      if (sp < 0) return sp;
+      if (!sp) OSD_HIP(launch_gn_silu(s, g2, l2.gw, gb));
+    }
     OSD_TRY(prof_mark(h, s));
     cur = ws.out[b];
     cur_w = l2.N;
@@ -706,16 +722,27 @@ static int chain_chunk(osd_handle* h, Slot& sl, const float* cond, int64_t n_tot
   const int64_t need_pad = (need + 63) / 64 * 64;
   // small batches: input_proj split-K (k_fused.hip) -- few output tiles, each a long sequential K loop
   int in_slices = 0;
+  static const int64_t splitk_target = [] { const char* e = getenv("OSD_INPUT_SPLITK_TARGET"); return e ? atol(e) : 768L; }();
   {
     const int64_t tiles = (int64_t)((a.H0 + 63) / 64) * ((m + 63) / 64);
     if (h->input_splitk > 0 && !h->splitk_suspended) in_slices = h->input_splitk;
     else if (h->input_splitk < 0 && !h->splitk_suspended && ldx >= 1024 && tiles < 384)      // fewer tiles than 1.5 per CU
-      in_slices = (int)std::min<int64_t>(16, std::max<int64_t>(2, (768 + tiles - 1) / tiles));
+      in_slices = (int)std::min<int64_t>(16, std::max<int64_t>(2, (splitk_target + tiles / 2) / tiles));
     in_slices = std::min(in_slices, ldx / 128);
     if (in_slices < 2) in_slices = 0;
   }
   const int64_t x_floats = padded ? (m * (int64_t)ldx + 63) / 64 * 64 : 0;
-  OSD_TRY(ensure_arena(&sl, need_pad + x_floats + (int64_t)in_slices * m * a.H0));
+  // ... and the deep Linear+GroupNorm layers likewise (same switch: the small-batch mode): slices so that a 512-wide layer has ~640
+  // workgroups (64 x 64 tiles)
+  int gn_slices = 0, max_c = a.H0;
+  for (int c : a.block_out) max_c = std::max(max_c, c);
+  if (in_slices > 0 && !(flags & OSD_F_TRAIN_MODE)) {
+    const int64_t tiles = (int64_t)((max_c + 63) / 64) * ((m + 63) / 64);
+    gn_slices = (int)std::min<int64_t>(4, (640 + tiles / 2) / tiles);
+    if (gn_slices < 4) gn_slices = 0;      // measured (dims 62 / 5054 / 26): 999 rows 257 -> 238 us per step with 4 slices; 3000 rows 351 -> 385 us with 2
+  }
+  const int64_t slab_floats = std::max<int64_t>((int64_t)in_slices * m * a.H0, gn_slices ? (int64_t)(gn_slices + 1) * m * max_c : 0);
+  OSD_TRY(ensure_arena(&sl, need_pad + x_floats + slab_floats));
   carve_fwd(a, sl.arena, m, false, &ws);
   float* x = padded ? sl.arena + need_pad : x_out + r0 * D;       // else the chain state lives in the output rows
   float* in_slabs = in_slices ? sl.arena + need_pad + x_floats : nullptr;
@@ -731,6 +758,7 @@ static int chain_chunk(osd_handle* h, Slot& sl, const float* cond, int64_t n_tot
   auto enqueue_step = [&](void) -> int {
     TrunkIn in{};
     in.x = x; in.ldx = ldx; in.kx = ldx; in.n = m; in.t_dev = sl.t_dev; in.in_slabs = in_slabs; in.in_slices = in_slices;
+    in.gn_slabs = in_slabs; in.gn_slices = gn_slices;
     in.ksplit = in_slices > 1;             // the small-batch mode already trades bit-equality with the chain kernel for latency: long-K layers on two wave groups
     in.train = train; in.seed = seed; in.row_offset = roff; in.drop_step_dev = sl.t_dev;
     OSD_TRY(run_trunk(h, s, ws, in));

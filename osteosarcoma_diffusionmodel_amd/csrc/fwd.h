@@ -9,6 +9,8 @@ namespace osd {
 struct TrunkIn {
   const float* x; int ldx; int64_t n;
   float* in_slabs; int in_slices; // > 1: input_proj split-K over that many slices (k_fused.hip), slabs = in_slices x n x H0 floats
+  float* gn_slabs; int gn_slices; // > 1: the >= 512-deep Linear+GroupNorm layers split K over workgroups (k_fused.hip: launch_gn_silu_splitk); slabs =
+                                 // (gn_slices + 1) x n x max width floats.  Eval-mode sampling of small batches only (another fp32 summation order)
   bool ksplit;                   // training-sized batches: ask for the two-wave-group GEMM variant (gemm_glds.h, NG = 2) in every layer
   bool a_unpacked;               // input_proj reads input_proj.weight itself (clamped at D, GemmArgs::a_kmax) instead of the packed copy;
                                  // x must then be zero in the columns [D, kx) (training: the library's own x_t buffer)

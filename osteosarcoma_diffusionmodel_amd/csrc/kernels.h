@@ -33,6 +33,8 @@ struct GnArgs {
 bool gn_width_supported(int gw);
 hipError_t launch_gn_silu(hipStream_t s, const GemmArgs& g, int gw, const GnArgs& a);        // drop_mode == 0
 hipError_t launch_gn_silu_drop(hipStream_t s, const GemmArgs& g, int gw, const GnArgs& a);   // drop_mode 1/2
+// k_fused.hip: small batches -- K slices over workgroups + a reduce / GroupNorm / SiLU kernel (another fp32 summation order: opt-in)
+hipError_t launch_gn_silu_splitk(hipStream_t s, const GemmArgs& g, const GnArgs& a, float* slabs, int slices);
 
 // k_elem.hip -----------------------------------------------------------------------
 hipError_t launch_set_int(hipStream_t s, int* p, int v);

@@ -401,6 +401,12 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
     OSD_HIP(dgrad(s, h->params[l1.w], Kt, l1.K1, W.g_z1[b], C, C, n, gdst, l1.K1, acc));
     if (l1.K2 > 0) OSD_HIP(dgrad(s, h->params[l1.w] + l1.K1, Kt, l1.K2, W.g_z1[b], C, C, n, W.g_out[skip_block], l1.K2, false));
   }
+  // Data parallel (bucket events requested): the encoder blocks' weight gradients go out NOW, in a grouped launch of their own, so
+  // that their buckets' events fire one launch before the end of the pass -- what stays behind the last launch, and so cannot
+  // overlap with any compute of this step, is the final bucket alone (input_proj + the conditioning branch: 2.1 MB of the 10.66 MB
+  // instead of 5.2 MB).  Two grouped launches of ~250 items each fill the machine less well than one of 500 (the work-item list
+  // is re-cut to the launch, wgrad_group.hip), so a single process keeps the one launch.
+  if (events) OSD_TRY(flush_all(false));
   // input_proj, time_proj, cond_proj, ConditionalEmbedding  (h0 = x W^T + b + t_emb[t] + c_proj)
   // h0 = x W^T + b_in + (t_emb W_t^T + b_t)[t] + (c W_c^T + b_c): the three biases share one gradient, the column sums of g_h0
   // (Tried: the conditioning branch's backward -- five dependent launches of 5-13 us -- and the affine-gradient column sums on the
