@@ -304,7 +304,7 @@ def validate_leg(model, dev, per_scenario=125_000):
 # ------------------------------------------------------------------------------------------------
 # training leg (BASELINE config 2 / 4)
 # ------------------------------------------------------------------------------------------------
-def train_leg(dev, dist, world, rank, steps, backend):
+def train_leg(dev, dist, world, rank, steps, backend, precision=None, epochs=True):
     """utils/train.py:204-250 per step on a device-resident synthetic dataset of 65 536 rows per rank (SURVEY section
     8d, config 2): mixup (host draws as the reference), osd_train_loss_fwd_bwd, bucketed all-reduce, fused clip+AdamW.
     Returns (per-rank dict).  `exposed_comm_ms` = time the handle's stream waits for the gradient exchange after its own
@@ -319,6 +319,7 @@ def train_leg(dev, dist, world, rank, steps, backend):
                         "save_frequency": 10, "val_split": 0.2, "random_seed": 42, "batch_size": B}
     torch.manual_seed(0)
     model = BiologyAwareDiffusionModel(50, 1900, 50, 3, conf)
+    model.precision = precision        # "bf16x3": the weight gradients of the step on the bf16 matrix pipe (csrc/wgrad_group.h); None: fp32
     tr = Trainer(model, [], [], conf, device=dev)
     model.train()
     g = torch.Generator(device=dev).manual_seed(42 + rank)
@@ -372,7 +373,7 @@ def train_leg(dev, dist, world, rank, steps, backend):
     # the same steps through Trainer.train_epoch over loaders shaped like prepare_data's (utils/train.py:413-437: random_split,
     # shuffle, drop_last, batch 4096): device-resident epoch path vs the reference's per-batch host hand-over
     epoch = None
-    if world == 1:
+    if world == 1 and epochs:
         from osteosarcoma_diffusionmodel_amd.train import OsteosarcomaDataset
         ds = object.__new__(OsteosarcomaDataset)
         ds.data, ds.conditions, ds.survival_days = data.cpu(), cond.cpu(), surv.cpu()
@@ -404,6 +405,16 @@ def train_leg(dev, dist, world, rank, steps, backend):
             "comm": None if world == 1 else f"{tr.comm_kind} ({backend})", "final_loss": round(float(loss.item()), 5),
             "epoch_samples_per_s": None if epoch is None else epoch["resident"]["samples_per_s"], "train_epoch": epoch,
             "includes": "mixup + q_sample + forward + backward + bucketed all-reduce + clip_grad_norm_ + AdamW, dropout 0.2 (Philox)"}
+
+
+def train_split_leg(dev, steps):
+    """The same training step with ``model.precision = "bf16x3"``: the grouped weight-gradient launch -- a quarter of the fp32 step,
+    leaves of the graph -- on the bf16 matrix pipe at fp32 accuracy (csrc/wgrad_group.h: operands split as they are staged); forward
+    and the dgrad chain stay fp32 (latency-bound launches of 10-50 us).  Opt-in, not the `train` figure."""
+    r = train_leg(dev, None, 1, 0, steps, None, precision="bf16x3", epochs=False)
+    return {"dtype": "weight gradients: bf16x3 split, f32 accumulate; forward / dgrad: f32", "ms_per_step": r["ms_per_step"],
+            "samples_per_s": r["samples_per_s"], "final_loss": r["final_loss"],
+            "effective_tflops": r["achieved_tflops"], "effective_vs_fp32_mfma_peak": r["frac_of_fp32_mfma_peak"]}
 
 
 def main():
@@ -479,6 +490,8 @@ def main():
         return
     if args.train_only:
         tr = train_leg(dev, dist, world, rank, args.train_steps, backend)
+        if world == 1 and not args.no_split:
+            tr["split_bf16"] = train_split_leg(dev, args.train_steps)
         if rank == 0:
             print(json.dumps({"train": tr}), flush=True)
         if dist is not None:
@@ -519,6 +532,8 @@ def main():
     train = None
     if not args.no_train and not args.profile_only:
         train = train_leg(dev, dist, world, rank, args.train_steps, backend)
+        if world == 1 and not args.no_split:
+            train["split_bf16"] = train_split_leg(dev, args.train_steps)
     refw = None
     if rank == 0 and world == 1 and not args.no_reference_workload and not args.profile_only:
         refw = reference_workload_leg(dev)

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <vector>
 #include "gemm_bf3.h"
+#include "b3_pack.h"
 #include "handle.h"
 #include "kernels.h"
 #include "fwd.h"

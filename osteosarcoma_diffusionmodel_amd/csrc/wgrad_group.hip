@@ -10,11 +10,14 @@ namespace osd {
 
 // A workgroup runs items blockIdx.x, blockIdx.x + gridDim.x, ...: one item each when the grid covers the list, or a walk
 // over it when the host caps the grid (to leave CU slots to a concurrent stream).
-__global__ __launch_bounds__(NTHREADS, 2) void wgrad_group_kernel(const WgItem* __restrict__ items, int n_items) {
+// MODE 1: 160 VGPRs and 48 KB of LDS -- up to three workgroups per CU
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS, MODE == 1 ? 3 : 2) void wgrad_group_kernel(const WgItem* __restrict__ items, int n_items) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const WgItem it = items[item];            // by value: the DMA asm statements clobber "memory"
-    wgrad_item(it, smem);
+    if constexpr (MODE == 1) wgrad_item_bf3(it, reinterpret_cast<uint4*>(smem));
+    else wgrad_item(it, smem);
   }
 }
 
@@ -109,7 +112,8 @@ int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::v
   WgPlanDev* pl = static_cast<WgPlanDev*>(h->wg_plans[plan_index]);
   const int dev = h->cfg.device;
   if (dev >= 0 && dev < 16 && !g_wg_attr[dev]) {
-    OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES));
+    OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_group_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES));
+    OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_group_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES));
     g_wg_attr[dev] = true;
   }
   // row range per item: about two workgroups per CU over the whole list, never fewer than 8 K steps per item
@@ -152,7 +156,9 @@ int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::v
   OSD_TRY(upload(s, reds, pl->reds, &pl->d_reds, &pl->cap_reds));
   const int n_items = (int)pl->items.size();
   const int grid = max_grid > 0 ? std::min(n_items, max_grid) : n_items;
-  hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)grid), dim3(NTHREADS), WG_LDS_BYTES, s, pl->d_items, n_items);
+  // precision 1 (bf16x3 split, gemm_bf3.h): the same items with both operands split into bf16 planes as they are staged
+  if (h->precision == 1) hipLaunchKernelGGL(wgrad_group_kernel<1>, dim3((unsigned)grid), dim3(NTHREADS), WG3_LDS_BYTES, s, pl->d_items, n_items);
+  else hipLaunchKernelGGL(wgrad_group_kernel<0>, dim3((unsigned)grid), dim3(NTHREADS), WG_LDS_BYTES, s, pl->d_items, n_items);
   OSD_HIP(hipGetLastError());
   if (!pl->reds.empty()) {
     hipLaunchKernelGGL(wgrad_group_reduce, dim3(64, (unsigned)pl->reds.size()), dim3(256), 0, s, pl->d_reds);

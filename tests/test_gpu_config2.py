@@ -87,7 +87,7 @@ def _assert_params_close(got, want, gclip, name):
     assert worst <= 0, f"param {name}: an element exceeds its propagated tolerance by {worst:.3e} (max|d|={d.max():.3e})"
 
 
-def _model(train_streams):
+def _model(train_streams, precision=None):
     sd = _inputs()[0]
     conf = config(FULL_H)
     conf["training"] = {"learning_rate": LR, "weight_decay": WD, "patience": 10, "min_delta": 1e-4,
@@ -97,6 +97,7 @@ def _model(train_streams):
     m.load_state_dict(sd, strict=False)
     m = m.cuda().train()
     m.train_streams = train_streams
+    m.precision = precision
     return m, conf
 
 
@@ -130,6 +131,28 @@ def test_config2_batch_grads_and_step_vs_oracle(train_streams, mask_mode, tmp_pa
         assert_close(osd["state"][i]["exp_avg"].cpu(), ref["m1"][k], 1e-4, atol=1e-12, what=f"exp_avg {k}")
         assert_close(osd["state"][i]["exp_avg_sq"].cpu(), ref["v1"][k], 2e-4, atol=1e-16, what=f"exp_avg_sq {k}")
         assert float(osd["state"][i]["step"]) == 1.0
+
+
+@pytest.mark.parametrize("mask_mode", ["injected", "philox"])
+def test_config2_weight_gradients_on_the_bf16_pipe_vs_oracle(mask_mode):
+    """``precision = "bf16x3"`` in training: every weight gradient of the step (the grouped launch, csrc/wgrad_group.h: both operands
+    split into three bf16 planes as they are staged, six bf16 MFMAs per product, fp32 accumulation) -- loss and all 52 gradients
+    against the oracle at the UNCHANGED config-2 tolerances, twice (cached work list).  Forward and the dgrad chain stay fp32."""
+    sd, x, cond, t, noise, injected = _inputs()
+    ref = _oracle(mask_mode)
+    kw = dict(t=t.cuda(), noise=noise.cuda())
+    if mask_mode == "injected":
+        kw["dropout_masks"] = [k.cuda() for k in injected]
+    else:
+        kw["seed"] = SEED
+    m, _ = _model(2, precision="bf16x3")
+    for rep in range(2):
+        m.zero_grad()
+        loss = m(x.cuda(), cond.cuda(), **kw)
+        loss.backward()
+        assert_close(loss.item(), ref["loss"], 1e-5, what="loss")
+        for k, p in m.named_parameters():
+            assert_close(p.grad.cpu(), ref["grads"][k], GRAD_RTOL, atol=1e-9, what=f"grad {k} (bf16x3 weight gradients, pass {rep})")
 
 
 def test_full_shape_trained_weights_chain_vs_oracle():

@@ -12,6 +12,7 @@
 #include <random>
 #include <algorithm>
 #include "gemm_bf3.h"
+#include "b3_pack.h"
 
 using namespace osd;
 
