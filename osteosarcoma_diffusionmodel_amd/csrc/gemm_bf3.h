@@ -634,22 +634,28 @@ __global__ __launch_bounds__(NTHREADS + 64 * LD, (LD || B3_RING == 2) ? 3 : 2) v
   asm volatile("s_barrier" ::: "memory");
   read_frags(f0, 0);
   if constexpr (LD == 0) { if (nkb > 2 && B3_RING == 3) b3_wait_vm<PPS>(); else b3_wait_vm<0>(); }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // lgkmcnt waits through the BUILTIN, not asm: hipcc's waitcnt pass does not see an asm wait, believes the fragment reads of the
+  // previous step still pending where the next MFMAs use them, and puts its own lgkmcnt(0) in front of those MFMAs -- which also
+  // waits for the reads issued a moment ago for the step after (seen in the ISA).  0xC07F = lgkmcnt(0), vmcnt / expcnt untouched.
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  asm volatile("s_barrier" ::: "memory");
 
   auto step = [&](const B3Frags& cur, B3Frags& nxt, int s) {
     // sched_barriers: without them hipcc sinks the MFMAs of stage s behind the next step's fragment reads (one register set
     // instead of two) and every step waits for its own LDS reads
     __builtin_amdgcn_sched_barrier(0);
     const bool last = s + 1 >= nkb;
-    if (!last && !(B3_EXP & 4)) read_frags(nxt, s1);
     const bool more = LD == 0 && s + B3_RING < nkb && !(B3_EXP & 1);
-    __builtin_amdgcn_sched_barrier(0);
+    // the DMA statements FIRST: hipcc follows an asm statement with s_waitcnt lgkmcnt(0) when LDS reads are pending, which would
+    // put the fragment reads of stage s + 1 in front of the MFMAs of stage s (seen in the ISA: every step waited for its LDS reads)
     if (more) issue_stage(s + B3_RING, s0);
     if constexpr (Epi::X_TILE) {
       // every stage has landed (the step before this one waited for vmcnt(0)) and every fragment read of the ring is complete:
       // the wave's x_t tile flies into its 16 KiB of the ring under the last MFMAs
       if (last && xt) Epi::xtile_issue(ea, ctx);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!last && !(B3_EXP & 4)) read_frags(nxt, s1);
     __builtin_amdgcn_sched_barrier(0);
     // one generator block per step (16 steps) or per other step (32 steps): sixteen per tile
     mfma_block((B3_EXP & 4) ? f0 : cur, rng && (NKB == 16 || !(s & 1)), NKB == 16 ? s : s / 2);
@@ -658,7 +664,7 @@ __global__ __launch_bounds__(NTHREADS + 64 * LD, (LD || B3_RING == 2) ? 3 : 2) v
       if (more && B3_RING == 3) b3_wait_vm<PPS>();
       else if (!(Epi::X_TILE && last && xt)) b3_wait_vm<0>();      // the x tile is waited for where the epilogue first needs it
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the fragments of stage s + 1 are in registers, every read of the ring is complete
     if (!(B3_EXP & 8)) asm volatile("s_barrier" ::: "memory");
     if (B3_RING == 3) { const int k = s0; s0 = s1; s1 = s2; s2 = k; }
     else { const int k = s0; s0 = s1; s1 = k; }
