@@ -71,6 +71,8 @@ def parse_args():
     ap.add_argument("--train-only", action="store_true", help="run only the training leg (for rocprofv3 --stats)")
     ap.add_argument("--no-reference-workload", action="store_true", help="skip the reference's default generation workload leg")
     ap.add_argument("--reference-workload-only", action="store_true")
+    ap.add_argument("--train-precision", default=None, choices=[None, "fp32", "bf16x3"],
+                    help="diagnostic (profiles): run the `train` leg itself under this precision instead of fp32 + a split_bf16 sub-leg")
     ap.add_argument("--no-split", action="store_true", help="skip the opt-in bf16x3 split-precision leg (roofline.split_bf16): the same workload with every GEMM "
                     "on the bf16 matrix pipe at fp32 accuracy; never the headline")
     ap.add_argument("--no-mid-size", action="store_true", help="skip the 32 768-patient comparison (LDS-resident chain kernel vs per-layer kernels) inside the roofline object")
@@ -489,8 +491,8 @@ def main():
             print(json.dumps({"validate": validate_leg(model, dev, args.validate_patients)}), flush=True)
         return
     if args.train_only:
-        tr = train_leg(dev, dist, world, rank, args.train_steps, backend)
-        if world == 1 and not args.no_split:
+        tr = train_leg(dev, dist, world, rank, args.train_steps, backend, precision=args.train_precision)
+        if world == 1 and not args.no_split and not args.train_precision:
             tr["split_bf16"] = train_split_leg(dev, args.train_steps)
         if rank == 0:
             print(json.dumps({"train": tr}), flush=True)

@@ -19,7 +19,22 @@ def frames(rows, seed):
 import pandas as pd
 pgm = pd.DataFrame(0, index=expr_cols, columns=[f"HALLMARK_{i}" for i in range(10)])
 for p in range(10): pgm.iloc[64 * p: 64 * p + 64, p] = 1
-r = frames(nr, 1); s = frames(n, 2)
+if len(sys.argv) > 3 and sys.argv[3] == "model":
+    # bench.py's validate leg: "real" = scenario 3 samples, "synthetic" = scenario 1 samples of a random-init model (heavy tails)
+    from bench import CONF, SCENARIOS
+    from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel
+    torch.manual_seed(0)
+    model = BiologyAwareDiffusionModel(50, 1900, 50, 3, CONF).cuda().eval()
+    rows = [[(sc["survival_time"] - 800) / 500, sc["event_occurred"], sc["metastasis_at_diagnosis"]] for sc in SCENARIOS]
+    def sample(seed, row, m):
+        cond = torch.tensor([row], dtype=torch.float32, device="cuda").repeat(m, 1)
+        x, mask = model.sample(cond, m, seed=seed, return_mutation_mask=True)
+        x = torch.nan_to_num(x, nan=0.0, posinf=1e6, neginf=-1e6)
+        x[:, :md] = mask
+        return (DeviceFrame(x[:, :md].contiguous(), mut_cols), DeviceFrame(x[:, md:md + ed].contiguous(), expr_cols), DeviceFrame(x[:, md + ed:].contiguous(), path_cols))
+    r = sample(777, rows[2], nr); s = sample(2000, rows[0], n)
+else:
+    r = frames(nr, 1); s = frames(n, 2)
 val.compute_mmd(torch.cat([f.values for f in r], 1)[:2048], torch.cat([f.values for f in s], 1)[:2048])
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
