@@ -97,7 +97,9 @@ int chain_pick_engine(osd_handle* h, int64_t n, int flags) {
   // patient-steps/s against 21.8 M for the per-layer engine, which also tiles the features; 512 tiles: 22.2 vs 22.1; beyond
   // that the chain kernel leads -- tools/probes/engine_crossover.py); below that, the LDS-resident chain where it leads
   if (n_tiles >= (int64_t)max_grid) return 1;
-  if (h->chain_variant != 1 && panel_window(h, n)) return 1;
+  if (h->chain_variant != 1 && h->chain_variant != 3 && panel_window(h, n)) return 1;
+  // small batches (the reference's own generation sizes): every 32-patient squad of the chain resident at once
+  if (squad_window(h, n)) return 1;
   return 0;
 }
 
@@ -195,6 +197,12 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
   const int T = a.T, H0 = a.H0;
   hipStream_t s = h->stream;
   OSD_TRY(chain_check_status(h));
+  // the squad chain: asked for by name, or auto's choice for a small batch (an explicit sampler = chain keeps the kernels that are
+  // bit-identical to the per-layer engine)
+  if (squad_window(h, n) && (h->chain_variant == 3 || h->sampler == 0)) {
+    h->last_chain_variant = 3;
+    return squad_chain_run(h, cond, n, x_T, noises, seed, row_offset, x_out, mut_mask_out);
+  }
   if (chain_use_panel(h, n)) {
     h->last_chain_variant = 2;
     return panel_chain_run(h, cond, n, x_T, noises, seed, row_offset, x_out, mut_mask_out);
@@ -383,6 +391,7 @@ void chain_free(osd_handle* h) {
   if (h->chain_args_dev) e = hipFree(h->chain_args_dev);
   if (h->abort_stream) { e = hipStreamDestroy(h->abort_stream); h->abort_stream = nullptr; }
   panel_chain_free(h);
+  squad_chain_free(h);
   h->chain_args_dev = nullptr;
   free(h->chain_args_host);
   h->chain_args_host = nullptr;

@@ -31,6 +31,13 @@ __global__ void k_pack_fragments(const float* __restrict__ w, int ldw, int F, in
   }
 }
 
+hipError_t launch_pack_fragments(hipStream_t s, const float* w, int ldw, int F, int K, int nfbg, int K8, float* dst) {
+  const long long total = (long long)nfbg * K8 * 64;
+  const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_pack_fragments, dim3(grid), dim3(256), 0, s, w, ldw, F, K, nfbg, K8, dst);
+  return hipGetLastError();
+}
+
 struct PanelPlan {
   bool ok = false;
   int n_layers = 0;

@@ -49,6 +49,13 @@ int panel_chain_pack(osd_handle* h, hipStream_t s);
 int panel_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, const float* noises, uint64_t seed, int64_t row_offset,
                     float* x_out, float* mut_mask_out);
 void panel_chain_free(osd_handle* h);
+hipError_t launch_pack_fragments(hipStream_t s, const float* w, int ldw, int F, int K, int nfbg, int K8, float* dst);
+// chain_squad.hip
+bool squad_chain_supported(const osd_handle* h);
+bool squad_window(osd_handle* h, int64_t n);
+int squad_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, const float* noises, uint64_t seed, int64_t row_offset,
+                    float* x_out, float* mut_mask_out);
+void squad_chain_free(osd_handle* h);
 // wgrad_group.hip
 struct WgPending;
 int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::vector<WgPending>& pend, float* slabs, int64_t slab_floats,

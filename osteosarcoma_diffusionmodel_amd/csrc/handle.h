@@ -154,11 +154,16 @@ struct osd_handle {
   unsigned long long* chain_stamps = nullptr;   // diagnostic builds (csrc/diag): device buffer of 8 counters per workgroup, else null
   int last_engine = 0;               // engine of the most recent osd_sample_chain (0 per-layer, 1 chain kernel)
   // LDS-resident variant of the chain kernel (chain_panel.h / chain_panel.hip)
-  int chain_variant = 0;             // osd_set_option("chain_variant"): 0 auto (chain.hip: chain_use_panel), 1 workspace chain (chain.h), 2 LDS-resident chain where the architecture fits (else 1)
+  int chain_variant = 0;             // osd_set_option("chain_variant"): 0 auto (chain.hip: chain_use_panel / squad_window), 1 workspace chain (chain.h),
+                                     // 2 LDS-resident chain where the architecture fits (else 1), 3 squad chain (chain_squad.h) where model and batch fit (else auto's choice without it)
   int last_chain_variant = 0;        // variant the most recent chain-kernel run used (osd_get_option)
   float* panel_wpk = nullptr; int64_t panel_wpk_floats = 0;   // fragment-ordered copies of the weights
   bool panel_wpk_valid = false;      // false after anything that may have changed the parameters: repacked by the next chain
   void* panel_args_dev = nullptr; void* panel_args_host = nullptr; int panel_args_cap = 0;
+  // small-batch variant (chain_squad.h / chain_squad.hip)
+  float* squad_wpk = nullptr; int64_t squad_wpk_floats = 0;
+  bool squad_wpk_valid = false;
+  void* squad_args_dev = nullptr; void* squad_args_host = nullptr; int squad_args_cap = 0;
   // bf16x3 split precision (gemm_bf3.h / split.hip)
   int precision = 0;                 // osd_set_option("precision"): 0 fp32 MFMA (default; the reference's arithmetic), 1 bf16x3 split on the bf16 matrix pipe
                                      // (fp32 accuracy, eval-mode sampling / forward of 256 / 512 wide trunks; everything else stays fp32)

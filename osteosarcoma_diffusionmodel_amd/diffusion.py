@@ -235,7 +235,9 @@ class BiologyAwareDiffusionModel(nn.Module):
         # which chain kernel: "workspace" (csrc/chain.h: 128-row tiles, activations through a private workspace -- the faster one from
         # 65 536 rows on), "panel" (csrc/chain_panel.h: 64 patients per workgroup, activations in LDS; bit-identical; at its full
         # rate from 16 384 rows on; architectures whose panels do not fit run the workspace kernel), None / "auto" (the library's choice:
-        # workspace from 65 536 rows on, panel from 10 240 rows on)
+        # workspace from 65 536 rows on, panel from 10 240 rows on, squad up to 3 072 rows), "squad" (csrc/chain_squad.h: eight workgroups per
+        # 32 patients, the small-batch kernel; agrees with the other engines to fp32 rounding, not bitwise; batches it cannot keep resident run
+        # on auto's other choices)
         self.chain_variant: Optional[str] = None
         self.last_chain_variant: Optional[str] = None     # the one the most recent chain-kernel sample() used
         self.chain_grid: Optional[int] = None             # workgroup count of the chain kernel (tests)
@@ -352,9 +354,9 @@ class BiologyAwareDiffusionModel(nn.Module):
             raise ValueError(f"sampler must be 'auto', 'chain' or 'graph', got {self.sampler!r}")
         L.check(L.lib().osd_set_option(eng.handle, b"sampler", mode))
         try:
-            variant = {None: 0, "auto": 0, "workspace": 1, "panel": 2}[self.chain_variant]
+            variant = {None: 0, "auto": 0, "workspace": 1, "panel": 2, "squad": 3}[self.chain_variant]
         except KeyError:
-            raise ValueError(f"chain_variant must be None, 'auto', 'workspace' or 'panel', got {self.chain_variant!r}")
+            raise ValueError(f"chain_variant must be None, 'auto', 'workspace', 'panel' or 'squad', got {self.chain_variant!r}")
         L.check(L.lib().osd_set_option(eng.handle, b"chain_variant", variant))
         try:
             prec = {None: 0, "fp32": 0, "f32": 0, "bf16x3": 1}[self.precision]
@@ -524,7 +526,7 @@ class BiologyAwareDiffusionModel(nn.Module):
         gave_up = counter(b"chain_fallbacks") > gave_up_before
         self.last_chain_variant = None
         if used == 1 or gave_up:
-            self.last_chain_variant = {1: "workspace", 2: "panel"}.get(counter(b"last_chain_variant"))
+            self.last_chain_variant = {1: "workspace", 2: "panel", 3: "squad"}.get(counter(b"last_chain_variant"))
         if gave_up:
             import warnings
             warnings.warn(L.last_error() or "the reverse-chain kernel gave up; the chain was re-run on the per-layer kernels")

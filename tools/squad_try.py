@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""The squad chain kernel (csrc/chain_squad.h) against the per-layer engine on the same seeds, then a timing of both.
+   squad_try.py [rows T [reps]]"""
+import sys, time
+import torch
+sys.path.insert(0, ".")
+from osteosarcoma_diffusionmodel_amd import BiologyAwareDiffusionModel
+from tests.helpers import FULL, FULL_H, config
+from bench import CONF, scenario_conditions
+
+
+def model(T, dims=None, seed=0):
+    torch.manual_seed(seed)
+    if dims:
+        conf = {"model": dict(CONF["model"])}; conf["model"]["diffusion"] = {"num_steps": T, "beta_schedule": "cosine"}
+        m = BiologyAwareDiffusionModel(dims[0], dims[1], dims[2], 3, conf).cuda().eval()
+    else:
+        m = BiologyAwareDiffusionModel(config=config(FULL_H, T=T), **FULL).cuda().eval()
+    return m
+
+
+T = 8
+for dims in (None, (62, 5054, 26), (10, 487, 5)):
+    m = model(T, dims)
+    for n in (32, 37, 999, 300):
+        cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(3)).cuda()
+        m.sampler, m.chain_variant, m.input_splitk = "graph", None, 0
+        ref, refm = m.sample(cond, n, return_mutation_mask=True, seed=77, row_offset=5)
+        m.sampler, m.chain_variant = "chain", "squad"
+        out, mask = m.sample(cond, n, return_mutation_mask=True, seed=77, row_offset=5)
+        d = (out - ref).abs().max().item()
+        print(f"dims={dims} n={n} ran={m.last_sampler}/{m.last_chain_variant} finite={bool(torch.isfinite(out).all())} "
+              f"max|d|={d:.3e} of {ref.abs().max().item():.3e} mask_equal={torch.equal(mask, refm)}", flush=True)
+        # injected draws
+        D = ref.shape[1]
+        z = torch.randn(T - 1, n, D, generator=torch.Generator().manual_seed(9)).cuda()
+        xT = torch.randn(n, D, generator=torch.Generator().manual_seed(10)).cuda()
+        m.sampler, m.chain_variant = "graph", None
+        ref2 = m.sample(cond, n, x_T=xT, noise=z)
+        m.sampler, m.chain_variant = "chain", "squad"
+        out2 = m.sample(cond, n, x_T=xT, noise=z)
+        print(f"   injected draws: ran={m.last_sampler}/{m.last_chain_variant} max|d|={(out2 - ref2).abs().max().item():.3e} of {ref2.abs().max().item():.3e}", flush=True)
+
+if len(sys.argv) > 1:
+    n, T = int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    m = model(T, (62, 5054, 26))
+    cond = scenario_conditions(n, 0).cuda()
+    for variant in ("graph", "squad") * (int(sys.argv[3]) if len(sys.argv) > 3 else 2):
+        if variant == "graph":
+            m.sampler, m.chain_variant, m.input_splitk = "graph", None, -1
+        else:
+            m.sampler, m.chain_variant = "chain", "squad"
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = m.sample(cond, n, seed=5)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"{variant:6s} n={n} T={T}: {dt*1e3:8.1f} ms  {dt/T*1e6:7.1f} us/step  {n/(dt/T*1000):8.0f} patients/s at T=1000  [{m.last_sampler}/{m.last_chain_variant}]", flush=True)
