@@ -61,11 +61,12 @@ static SquadPlan make_plan(const Arch& a) {
   p.n_layers = (int)a.layers.size();
   p.last_in = cur;
   p.K8_out = cur_w / 8;
-  if (p.K8_out * 256 > SQ_STAGE_FLOATS) return p;
+  if (p.K8_out != 32) return p;                                // the operand of output_proj: 32 KB of LDS beside the K-split partials
   p.in_off = woff; woff += (int64_t)(a.H0 / 32) * (4 * p.T32) * 256;
   p.out_off = woff; woff += (int64_t)p.T32 * p.K8_out * 256;
   p.bias_off = woff; woff += (int64_t)p.T32 * 32;
   p.wpk_floats = woff;
+  if (woff * 4 >= (int64_t)1 << 31) return p;                  // byte offsets into the packed weights are ints
   p.act_floats = (off + 63) / 64 * 64;
   p.ok = true;
   return p;
@@ -73,24 +74,28 @@ static SquadPlan make_plan(const Arch& a) {
 
 bool squad_chain_supported(const osd_handle* h) { return make_plan(h->arch).ok; }
 
-struct SquadDev { int occ[3] = {0, 0, 0}; int cus = 0; bool ready = false; };
+struct SquadDev { int occ[3] = {0, 0, 0}; int cus = 0; int lds = 0; bool ready = false; };      // occupancies at `lds` bytes of dynamic LDS
 static SquadDev g_squad_dev[16];
 
 template <int WPC>
-static int squad_occ(int* occ) {
-  OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(squad_chain_kernel<WPC>), hipFuncAttributeMaxDynamicSharedMemorySize, SQ_LDS_BYTES));
-  OSD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, squad_chain_kernel<WPC>, SQ_THREADS, SQ_LDS_BYTES));
+static int squad_occ(int* occ, int lds) {
+  OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(squad_chain_kernel<WPC>), hipFuncAttributeMaxDynamicSharedMemorySize, sq_lds_bytes(SQ_MAX_LAYERS)));
+#ifdef OSD_DIAG
+  if (WPC == 1) OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(squad_chain_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sq_lds_bytes(SQ_MAX_LAYERS)));
+#endif
+  OSD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, squad_chain_kernel<WPC>, SQ_THREADS, lds));
   if (*occ > WPC) *occ = WPC;
   return OSD_OK;
 }
 
-static int squad_device(int device, SquadDev** out) {
+static int squad_device(int device, int lds, SquadDev** out) {
   if (device < 0 || device >= 16) { set_error("device %d out of range", device); return OSD_EINVAL; }
   SquadDev& d = g_squad_dev[device];
-  if (!d.ready) {
-    OSD_TRY(squad_occ<1>(&d.occ[0]));
-    OSD_TRY(squad_occ<2>(&d.occ[1]));
-    OSD_TRY(squad_occ<3>(&d.occ[2]));
+  if (!d.ready || d.lds != lds) {
+    OSD_TRY(squad_occ<1>(&d.occ[0], lds));
+    OSD_TRY(squad_occ<2>(&d.occ[1], lds));
+    OSD_TRY(squad_occ<3>(&d.occ[2], lds));
+    d.lds = lds;
     hipDeviceProp_t prop;
     OSD_HIP(hipGetDeviceProperties(&prop, device));
     d.cus = prop.multiProcessorCount;
@@ -103,7 +108,7 @@ static int squad_device(int device, SquadDev** out) {
 // Workgroups per CU (1..3) that make every squad of an n-row chain resident at once; 0 = the batch is too large for this kernel.
 static int squad_wpc(osd_handle* h, int64_t n) {
   SquadDev* d = nullptr;
-  if (squad_device(h->cfg.device, &d) != OSD_OK) { (void)hipGetLastError(); return 0; }
+  if (squad_device(h->cfg.device, sq_lds_bytes((int)h->arch.layers.size()), &d) != OSD_OK) { (void)hipGetLastError(); return 0; }
   const int64_t wgs = (n + SQ_RP - 1) / SQ_RP * SQ_S;
   for (int w = 1; w <= 3; ++w)
     if (d->occ[w - 1] >= w && wgs <= (int64_t)w * d->cus) return w;
@@ -174,17 +179,19 @@ int squad_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_
   sa.status = h->chain_sync;
   sa.bar = h->chain_sync + 4 + 2048;
   sa.spin_budget = h->chain_spin_budget;
+  sa.stamps = h->chain_stamps;
 
   for (int l = 0; l < p.n_layers; ++l) {
     SquadLayer& L = p.L[l];
     const LayerDesc& ld = a.layers[l];
-    L.wpk = h->squad_wpk + p.wpk_off[l];
+    L.w_off = (int)p.wpk_off[l];
     L.bias = h->params[ld.b]; L.gamma = h->params[ld.gamma]; L.beta = h->params[ld.beta];
     sa.L[l] = L;
   }
   sa.n_layers = p.n_layers;
-  sa.wpk_in = h->squad_wpk + p.in_off; sa.bias_in = h->params[a.pm.in_b]; sa.H0 = H0;
-  sa.wpk_out = h->squad_wpk + p.out_off; sa.bias_out = h->squad_wpk + p.bias_off;
+  sa.wpk = h->squad_wpk; sa.wpk_floats = p.wpk_floats;
+  sa.in_off = (int)p.in_off; sa.bias_in = h->params[a.pm.in_b]; sa.H0 = H0;
+  sa.out_off = (int)p.out_off; sa.bias_out = h->squad_wpk + p.bias_off;
   sa.T32 = p.T32; sa.h0_out = p.h0_out; sa.last_in = p.last_in; sa.K8_out = p.K8_out;
   sa.x = x_out; sa.ldx = D; sa.D = D; sa.n = (int)n;
   sa.cproj = cw.cproj; sa.ldc = H0; sa.temb = h->d_temb; sa.ldt = H0; sa.coef = h->d_coef;
@@ -206,6 +213,7 @@ int squad_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_
   }
   SquadArgs* const host_args = static_cast<SquadArgs*>(h->squad_args_host);
   const int grid = n_panels * SQ_S;
+  const int lds = sq_lds_bytes(p.n_layers);
   int launch = 0;
   for (int done = 0; done < T; done += seg) {
     sa.t_first = T - 1 - done;
@@ -215,9 +223,13 @@ int squad_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_
     const SquadArgs* dargs = static_cast<const SquadArgs*>(h->squad_args_dev) + launch;
     OSD_HIP(hipMemcpyAsync(const_cast<SquadArgs*>(dargs), &host_args[launch], sizeof(SquadArgs), hipMemcpyHostToDevice, s));
     ++launch;
-    if (wpc == 1) hipLaunchKernelGGL(squad_chain_kernel<1>, dim3(grid), dim3(SQ_THREADS), SQ_LDS_BYTES, s, dargs);
-    else if (wpc == 2) hipLaunchKernelGGL(squad_chain_kernel<2>, dim3(grid), dim3(SQ_THREADS), SQ_LDS_BYTES, s, dargs);
-    else hipLaunchKernelGGL(squad_chain_kernel<3>, dim3(grid), dim3(SQ_THREADS), SQ_LDS_BYTES, s, dargs);
+#ifdef OSD_DIAG
+    if (sa.stamps && wpc == 1) hipLaunchKernelGGL((squad_chain_kernel<1, true>), dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
+    else
+#endif
+    if (wpc == 1) hipLaunchKernelGGL(squad_chain_kernel<1>, dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
+    else if (wpc == 2) hipLaunchKernelGGL(squad_chain_kernel<2>, dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
+    else hipLaunchKernelGGL(squad_chain_kernel<3>, dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
     OSD_HIP(hipGetLastError());
   }
   h->chain_pending = true;

@@ -22,7 +22,7 @@ def model(T, dims=None, seed=0):
 T = 8
 for dims in (None, (62, 5054, 26), (10, 487, 5)):
     m = model(T, dims)
-    for n in (32, 37, 999, 300):
+    for n in (32, 37, 999, 300, 1500, 3000):
         cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(3)).cuda()
         m.sampler, m.chain_variant, m.input_splitk = "graph", None, 0
         ref, refm = m.sample(cond, n, return_mutation_mask=True, seed=77, row_offset=5)
