@@ -811,7 +811,7 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
   h->last_precision = split ? 1 : 0;
   if (split) OSD_TRY(split_prepare(h, h->stream));
   h->last_engine = split ? 0 : chain_pick_engine(h, n, flags);
-  if (h->last_engine == 1 && noises && h->w_out_packed) h->last_engine = 0;      // injected draws at D % 4 != 0: guarded per-layer kernels
+  if (h->last_engine == 1 && noises && h->w_out_packed && !chain_uses_squad(h, n)) h->last_engine = 0;      // injected draws at D % 4 != 0: guarded per-layer kernels (the squad chain reads any layout)
   bool fell_back = false;
   if (h->last_engine == 1) {
     OSD_TRY(chain_run(h, cond, n, x_T, noises, seed, row_offset, x_out, mut_mask_out));
@@ -863,7 +863,8 @@ int osd_sample_chain(osd_handle* h, const float* cond, int64_t n, const float* x
   if (rc != OSD_OK) return rc;
   if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(h->stream));
   if (fell_back)       // a warning, not an error: osd_last_error() tells what happened, osd_get_option("chain_fallbacks") counts
-    set_error("warning: the reverse-chain kernel gave up in a dependency wait; the chain was re-run on the per-layer kernels (same results)");
+    set_error("warning: the reverse-chain kernel gave up in a dependency wait; the chain was re-run on the per-layer kernels (%s)",
+              h->last_chain_variant == 3 ? "results agree with the squad chain's to fp32 rounding" : "same results");
   return OSD_OK;
 }
 

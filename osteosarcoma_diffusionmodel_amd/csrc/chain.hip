@@ -84,6 +84,10 @@ static bool chain_use_panel(osd_handle* h, int64_t n) {
   return panel_window(h, n);
 }
 
+// The squad chain: asked for by name, or auto's choice for a small batch (an explicit sampler = chain keeps the kernels that are
+// bit-identical to the per-layer engine).
+bool chain_uses_squad(osd_handle* h, int64_t n) { return squad_window(h, n) && (h->chain_variant == 3 || h->sampler == 0); }
+
 // 0 = per-layer kernels (eager or hipGraph), 1 = persistent chain kernel
 int chain_pick_engine(osd_handle* h, int64_t n, int flags) {
   if (h->sampler == 2) return 0;
@@ -197,9 +201,7 @@ int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, con
   const int T = a.T, H0 = a.H0;
   hipStream_t s = h->stream;
   OSD_TRY(chain_check_status(h));
-  // the squad chain: asked for by name, or auto's choice for a small batch (an explicit sampler = chain keeps the kernels that are
-  // bit-identical to the per-layer engine)
-  if (squad_window(h, n) && (h->chain_variant == 3 || h->sampler == 0)) {
+  if (chain_uses_squad(h, n)) {
     h->last_chain_variant = 3;
     return squad_chain_run(h, cond, n, x_T, noises, seed, row_offset, x_out, mut_mask_out);
   }

@@ -173,13 +173,11 @@ __device__ __forceinline__ bool squad_wait(const unsigned* word, unsigned want, 
   for (unsigned it = 1;; ++it) {
     __builtin_amdgcn_s_sleep(1);
     if ((unsigned)__builtin_amdgcn_readfirstlane((int)ld_relaxed_agent(word)) >= want) return true;
-    if ((it & 63u) == 0) {                                   // the failure checks every 64th poll
-      if ((unsigned)__builtin_amdgcn_readfirstlane((int)ld_relaxed_agent(status)) != CHAIN_OK) return false;
-      if (__builtin_amdgcn_s_memrealtime() - t0 > budget) {
-        if (lane == 0) st_relaxed_agent(status, CHAIN_TIMEOUT);
-        return false;
-      }
+    if (__builtin_amdgcn_s_memrealtime() - t0 > budget) {
+      if (lane == 0) st_relaxed_agent(status, CHAIN_TIMEOUT);
+      return false;
     }
+    if ((it & 31u) == 0 && (unsigned)__builtin_amdgcn_readfirstlane((int)ld_relaxed_agent(status)) != CHAIN_OK) return false;      // a partner gave up / the host's abort
   }
 }
 

@@ -35,6 +35,7 @@ int check_rows(int64_t n);
 // chain.hip
 bool chain_supported(const Arch& a);
 int chain_pick_engine(osd_handle* h, int64_t n, int flags);
+bool chain_uses_squad(osd_handle* h, int64_t n);
 int chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, const float* noises, uint64_t seed, int64_t row_offset,
               float* x_out, float* mut_mask_out);
 int chain_check_status(osd_handle* h);
