@@ -84,9 +84,14 @@ static bool chain_use_panel(osd_handle* h, int64_t n) {
   return panel_window(h, n);
 }
 
-// The squad chain: asked for by name, or auto's choice for a small batch (an explicit sampler = chain keeps the kernels that are
-// bit-identical to the per-layer engine).
-bool chain_uses_squad(osd_handle* h, int64_t n) { return squad_window(h, n) && (h->chain_variant == 3 || h->sampler == 0); }
+// The squad chain: asked for by name, or auto's choice for a small batch in the small-batch mode (osd_set_option("input_splitk",
+// != 0): the switch that already trades "results do not depend on the batch size, bit for bit" for latency; the library default
+// keeps that invariance, utils/generate.py's front end turns the mode on).  An explicit sampler = chain keeps the kernels that
+// are bit-identical to the per-layer engine.
+bool chain_uses_squad(osd_handle* h, int64_t n) {
+  if (!squad_window(h, n)) return false;
+  return h->chain_variant == 3 || (h->sampler == 0 && h->input_splitk != 0 && !h->splitk_suspended);
+}
 
 // 0 = per-layer kernels (eager or hipGraph), 1 = persistent chain kernel
 int chain_pick_engine(osd_handle* h, int64_t n, int flags) {
@@ -102,8 +107,8 @@ int chain_pick_engine(osd_handle* h, int64_t n, int flags) {
   // that the chain kernel leads -- tools/probes/engine_crossover.py); below that, the LDS-resident chain where it leads
   if (n_tiles >= (int64_t)max_grid) return 1;
   if (h->chain_variant != 1 && h->chain_variant != 3 && panel_window(h, n)) return 1;
-  // small batches (the reference's own generation sizes): every 32-patient squad of the chain resident at once
-  if (squad_window(h, n)) return 1;
+  // small batches (the reference's own generation sizes) in the small-batch mode: every 32-patient squad of the chain resident at once
+  if (chain_uses_squad(h, n)) return 1;
   return 0;
 }
 

@@ -107,13 +107,18 @@ def test_squad_chain_agrees_with_the_per_layer_kernels(dims, n):
 
 
 def test_auto_picks_the_squad_chain_for_small_batches_only():
-    """auto: batches whose squads are all resident at once (8 workgroups per 32 patients, three workgroups per CU: 3 072 rows on 256
-    CUs) run on the squad chain; larger ones keep their engines; models outside its decomposition (H0 != 256, a 128-wide block,
-    fewer than 8 state tiles) never see it; an explicit sampler = "chain" keeps the bit-identical chain kernels."""
+    """auto in the small-batch mode (input_splitk != 0: SyntheticPatientGenerator's default for its own model): batches whose
+    squads are all resident at once (8 workgroups per 32 patients, three workgroups per CU: 3 072 rows on 256 CUs) run on the squad
+    chain; larger ones keep their engines; the library default (input_splitk = 0: results independent of the batch size bit for
+    bit) never picks it; models outside its decomposition (H0 != 256, a 128-wide block, fewer than 8 state tiles) never see it; an
+    explicit sampler = "chain" keeps the bit-identical chain kernels."""
     T = 4
     m = _model(T, seed=1)
     cond = torch.randn(6144, 3, generator=torch.Generator().manual_seed(1)).cuda()
     m.sampler, m.chain_variant = "auto", None
+    m.sample(cond[:333], 333, seed=2)                 # input_splitk = 0 (from _model)
+    assert m.last_sampler == "graph"
+    m.input_splitk = -1
     for n, want in ((333, ("chain", "squad")), (3000, ("chain", "squad")), (6144, ("graph", None))):
         m.sample(cond[:n], n, seed=2)
         assert (m.last_sampler, m.last_chain_variant) == want, n
