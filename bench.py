@@ -209,7 +209,8 @@ def reference_workload_leg(dev):
             assert all(r["expression"].shape == (per, dims[1]) for r in res.values())
             n = per * len(scen)
             out["runs"].append({"dims": list(dims), "D": D, "patients_per_scenario": per, "patients": n, "T": 1000,
-                                "seconds": round(dt, 4), "patients_per_s": round(n / dt, 1), "engine": model.last_sampler,
+                                "seconds": round(dt, 4), "patients_per_s": round(n / dt, 1),
+                                "engine": model.last_sampler + ("/" + model.last_chain_variant if model.last_chain_variant else ""),
                                 "achieved_tflops": round(n * 1000 * flop_row_step / dt / 1e12, 2),
                                 "frac_of_fp32_mfma_peak": round(n * 1000 * flop_row_step / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                                 "vs_quickstart_gpu": round(n / dt / 3.3, 1)})
