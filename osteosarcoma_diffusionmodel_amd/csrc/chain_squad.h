@@ -146,6 +146,7 @@ __device__ __forceinline__ void sq_kloop(f32x16 (&acc)[NFB][1], v4f (&aq)[SQ_DEP
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb) aq[d][fb] = la(fb, in);
       bq[d] = lb(in);
+      __builtin_amdgcn_sched_barrier(0);              // the refills stay in slot order: every wait in the loop is "all but the youngest ones"
     }
   };
   int i0 = 0;
@@ -472,6 +473,12 @@ __global__ __launch_bounds__(SQ_THREADS, WPC) void squad_chain_kernel(const Squa
       const int nt = t1 - t0, rem = nt & 3;
       const int rounds = (nt >> 2) + (rem == 3 ? 1 : 0), n_split = rem == 3 ? 0 : rem;
       auto tile_a = [&](int tile) { return a.out_off * 4 + tile * K8o * 1024; };      // bytes, uniform
+      const int n8s = K8o / 4;                    // a wave's 8-k blocks of a K-split tile
+      auto split_prime = [&](int r) {
+        const int wo = tile_a(t0 + 4 * rounds + r) + (wave * n8s) * 1024;
+        sq_prime_a<1, SQ_DEPTH>(aq, n8s, [&](int, int i) -> v4f { return sq_ld(r_w, l16, wo + i * 1024); });
+      };
+      if (rounds == 0 && n_split > 0) split_prime(0);
       {
         const int tile0 = t0 + wave;
         if (rounds > 0 && tile0 < t1) {
@@ -500,6 +507,8 @@ __global__ __launch_bounds__(SQ_THREADS, WPC) void squad_chain_kernel(const Squa
         if (j + 1 < rounds && tile_n < t1) {
           const int wn = tile_a(tile_n);
           sq_prime_a<1, SQ_DEPTH>(aq, K8o, [&](int, int i) -> v4f { return sq_ld(r_w, l16, wn + i * 1024); });
+        } else if (j + 1 == rounds && n_split > 0) {
+          split_prime(0);
         }
         SQ_STAMP(8);
 #pragma unroll
@@ -508,11 +517,10 @@ __global__ __launch_bounds__(SQ_THREADS, WPC) void squad_chain_kernel(const Squa
       }
       for (int r = 0; r < n_split; ++r) {
         const int tile = t0 + 4 * rounds + r;
-        const int n8q = K8o / 4;
+        const int n8q = n8s;
         const int wo = tile_a(tile) + (wave * n8q) * 1024;
         auto la = [&](int fb, int i) -> v4f { (void)fb; return sq_ld(r_w, l16, wo + i * 1024); };
         auto lbq = [&](int i) -> v4f { return *reinterpret_cast<const v4f*>(stage + ((wave * n8q + i) * 64 + lane) * 4); };
-        sq_prime_a<1, SQ_DEPTH>(aq, n8q, la);
         const v4f xw_ = sq_ld(r_xs, l16, (4 * tile + wave) * 1024);                      // unit q = wave is this wave's to finish
         const float4 xw = make_float4(xw_.x, xw_.y, xw_.z, xw_.w);
         const float4 bw = ldg4(a.bias_out + 32 * tile + 8 * wave + 4 * h);
@@ -520,6 +528,7 @@ __global__ __launch_bounds__(SQ_THREADS, WPC) void squad_chain_kernel(const Squa
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[0][0][i] = 0.f;
         sq_kloop<1, SQ_DEPTH>(acc, aq, n8q, la, lbq);
+        if (r + 1 < n_split) split_prime(r + 1);
         // every wave hands the three units it does not finish to their owners: red[q][slot of the writer among the other three][lane]
         float* const red = stage + 32 * 256;
         if (r > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the previous left-over tile's partials have been read
