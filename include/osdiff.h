@@ -94,15 +94,22 @@ int osd_set_stream(osd_handle *h, void *hip_stream);
  * the dgrad epilogue), "chain_variant" (which chain kernel: 1 the workspace chain, 128-row tiles whose activations
  * pass through a private workspace -- the faster one from 65 536 rows on; 2 the LDS-resident chain, 64 patients per workgroup
  * with every activation in LDS, bit-identical, for architectures whose panels fit -- hidden_dims[0] = 256 = the last block's
- * width --, others fall back to 1; it runs at its full rate from 16 384 rows on; 0 auto: 1 from 65 536 rows on, 2 from 10 240 rows on), "dual_dgrad" / "train_ksplit" /
- * "train_input_splitk" (training-step experiments).  Auto sampler: the chain kernel when the batch has at least as many 128-row tiles as the device
+ * width --, others fall back to 1; it runs at its full rate from 16 384 rows on; 3 the squad chain, the small-batch kernel: eight
+ * workgroups per 32 patients for the whole chain, for models it decomposes ("squad_chain_supported") and batches whose squads are all
+ * resident -- 3 072 rows on 256 CUs --, others run what auto would; it agrees with the other engines to fp32 rounding, not bitwise;
+ * 0 auto: 1 from 65 536 rows on, 2 from 10 240 rows on, 3 for resident batches when "input_splitk" != 0), "dual_dgrad" / "train_ksplit" /
+ * "train_input_splitk" (training-step experiments), "input_splitk" (the small-batch mode of sampling: 0 off --
+ * the default: a row's result does not depend on the batch it is in, bit for bit --, -1 auto, n > 0 slices: small batches run
+ * input_proj and the deep layers split over K, or, where chain_variant 3 applies, the squad chain; another fp32 summation order,
+ * chain tolerance against the default).  Auto sampler: the chain kernel when the batch has at least as many 128-row tiles as the device
  * holds resident workgroups (65 536 rows on an MI355X) or falls into the LDS-resident kernel's window (above), and the model is
  * in eval mode; else the per-layer kernels. */
 int osd_set_option(osd_handle *h, const char *name, int64_t value);
 
 /* Reads an option back, or one of the read-only counters "chain_fallbacks" (chains that gave up -- see osd_sample_chain --
- * and were re-run on the per-layer kernels), "last_engine" (0 per-layer kernels, 1 chain kernel), "last_chain_variant" (1 | 2,
- * the chain kernel that ran last) and "panel_chain_supported" (1 when "chain_variant" 2 applies to this model).  Further options:
+ * and were re-run on the per-layer kernels), "last_engine" (0 per-layer kernels, 1 chain kernel), "last_chain_variant" (1 | 2 | 3,
+ * the chain kernel that ran last), "panel_chain_supported" / "squad_chain_supported" (1 when "chain_variant" 2 / 3 applies to this
+ * model).  Further options:
  * "chain_spin_budget" (ticks of the 100 MHz s_memrealtime counter a dependency wait inside the chain kernel may take, default
  * 5 s), "chain_wall_budget_ms" (host-side budget of a synchronous chain; 0 = 10 x the estimated run time + 2 s). */
 int osd_get_option(osd_handle *h, const char *name, int64_t *value);
