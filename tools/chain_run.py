@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run the reverse chain once at a chosen T (diagnostic target of rocprofv3 passes): chain_run.py <rows> <T> <sampler|split> [workspace|panel].
+"""Run the reverse chain once at a chosen T (diagnostic target of rocprofv3 passes): chain_run.py <rows> <T> <sampler|split> [workspace|panel|squad].
 `split` = the bf16x3 precision (per-layer launches on planes buffers, csrc/split.hip)."""
 import sys
 from pathlib import Path

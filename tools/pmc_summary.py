@@ -8,6 +8,7 @@ dur = collections.defaultdict(list)
 
 
 def klass(name):
+    if "squad_chain_kernel" in name: return "squad_chain_kernel"
     if "panel_chain_kernel" in name: return "panel_chain_kernel"
     if "chain_kernel" in name: return "chain_kernel"
     if "wgrad_group_kernel" in name: return "wgrad_group_kernel"
@@ -52,7 +53,7 @@ for k in sorted(vals):
     n = len(vals[k].get("GRBM_GUI_ACTIVE", []))
     print(f"| {k} | {n} | {sum(dur[k]) / max(len(dur[k]), 1) / 1e6:.3f} | {busy:.3f} | {avg(k, 'SQ_LDS_BANK_CONFLICT'):.0f} | {fetch:.0f} | {write:.0f} | "
           f"{tr / 1e6:.1f} | {hit / (hit + miss):.3f} | {avg(k, 'SQ_INSTS_VALU'):.0f} |")
-units = {k: (chain_units if k in ("chain_kernel", "panel_chain_kernel") else 32768.0) for k in traffic}
+units = {k: (chain_units if k in ("chain_kernel", "panel_chain_kernel") else (2976.0 * 100 if k == "squad_chain_kernel" else 32768.0)) for k in traffic}      # squad pass: chain_run.py 2976 100
 # the library these counters were collected on: bench.py only quotes a traffic figure for the build it is running (sha256 of the .so)
 import hashlib, os
 from pathlib import Path
