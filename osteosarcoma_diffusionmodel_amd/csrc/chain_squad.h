@@ -357,7 +357,7 @@ __global__ __launch_bounds__(SQ_THREADS, WPC) void squad_chain_kernel(const Squa
         SQ_STAMP(4);
         // All four partial accumulators -> LDS as [wave][patient][feature] (row stride 4 mod 32 dwords: the b128 accesses of both
         // sides spread over the banks).  Then the epilogue runs on all 256 threads, 8 threads per patient: thread (row, c) owns
-        // features 4 NFB c .. + 4 NFB - 1 of the group -- sum of the partials in wave order, bias, the row's GroupNorm statistics over
+        // features 4 c .. + 3 of every 32-feature block of the group -- sum of the partials in wave order, bias, the row's GroupNorm statistics over
         // its 8 lanes (DPP), SiLU (chain_gn_silu's formulas; one wave doing the whole tile measured 1.0 us per layer).
         constexpr int LDP = 32 * NFB + 4, NE = 4 * NFB, GW = 32 * NFB;
 #pragma unroll
@@ -368,18 +368,18 @@ __global__ __launch_bounds__(SQ_THREADS, WPC) void squad_chain_kernel(const Squa
                 make_float4(acc[fb][0][4 * q], acc[fb][0][4 * q + 1], acc[fb][0][4 * q + 2], acc[fb][0][4 * q + 3]);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         {
-          const int erow = tid >> 3, c = tid & 7, f0 = NE * c;
+          const int erow = tid >> 3, c = tid & 7, f0 = 4 * c;      // the thread's j-th float4: features 32 j + 4 c .. + 3 (8 lanes = one 128-byte row: no bank conflicts)
           const float* pl = prm + l * SQ_PRM;
           float v[NE];
 #pragma unroll
           for (int j = 0; j < NFB; ++j) {
-            float4 sum = *reinterpret_cast<const float4*>(stage + erow * LDP + f0 + 4 * j);
+            float4 sum = *reinterpret_cast<const float4*>(stage + erow * LDP + f0 + 32 * j);
 #pragma unroll
             for (int w = 1; w < 4; ++w) {
-              const float4 pv = *reinterpret_cast<const float4*>(stage + (w * 32 + erow) * LDP + f0 + 4 * j);
+              const float4 pv = *reinterpret_cast<const float4*>(stage + (w * 32 + erow) * LDP + f0 + 32 * j);
               sum.x += pv.x; sum.y += pv.y; sum.z += pv.z; sum.w += pv.w;
             }
-            const float4 bv = *reinterpret_cast<const float4*>(pl + f0 + 4 * j);
+            const float4 bv = *reinterpret_cast<const float4*>(pl + f0 + 32 * j);
             v[4 * j] = sum.x + bv.x; v[4 * j + 1] = sum.y + bv.y; v[4 * j + 2] = sum.z + bv.z; v[4 * j + 3] = sum.w + bv.w;
           }
           float sm = 0.f;
@@ -392,14 +392,14 @@ __global__ __launch_bounds__(SQ_THREADS, WPC) void squad_chain_kernel(const Squa
           const float rstd = 1.0f / sqrtf(sq_sum8(qs) * (1.0f / GW) + GN_EPS);
 #pragma unroll
           for (int j = 0; j < NFB; ++j) {
-            const float4 gv = *reinterpret_cast<const float4*>(pl + 64 + f0 + 4 * j);
-            const float4 bev = *reinterpret_cast<const float4*>(pl + 128 + f0 + 4 * j);
+            const float4 gv = *reinterpret_cast<const float4*>(pl + 64 + f0 + 32 * j);
+            const float4 bev = *reinterpret_cast<const float4*>(pl + 128 + f0 + 32 * j);
             v4f y;
             y.x = silu_f(fmaf((v[4 * j] - mean) * rstd, gv.x, bev.x));
             y.y = silu_f(fmaf((v[4 * j + 1] - mean) * rstd, gv.y, bev.y));
             y.z = silu_f(fmaf((v[4 * j + 2] - mean) * rstd, gv.z, bev.z));
             y.w = silu_f(fmaf((v[4 * j + 3] - mean) * rstd, gv.w, bev.w));
-            const int f = f0 + 4 * j;                       // feature inside the group: unit (f / 8), half (f / 4) & 1
+            const int f = f0 + 32 * j;                      // feature inside the group: unit (f / 8), half (f / 4) & 1
             const int unit = g * NFB * 4 + (f >> 3), ln = erow + 32 * ((f >> 2) & 1);
             sq_st_sc1(r_act, 16 * ln, L.out * 4 + unit * 1024, y);
           }

@@ -81,7 +81,7 @@ template <int WPC>
 static int squad_occ(int* occ, int lds) {
   OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(squad_chain_kernel<WPC>), hipFuncAttributeMaxDynamicSharedMemorySize, sq_lds_bytes(SQ_MAX_LAYERS)));
 #ifdef OSD_DIAG
-  if (WPC == 1) OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(squad_chain_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sq_lds_bytes(SQ_MAX_LAYERS)));
+  OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(squad_chain_kernel<WPC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, sq_lds_bytes(SQ_MAX_LAYERS)));
 #endif
   OSD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, squad_chain_kernel<WPC>, SQ_THREADS, lds));
   if (*occ > WPC) *occ = WPC;
@@ -225,6 +225,8 @@ int squad_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_
     ++launch;
 #ifdef OSD_DIAG
     if (sa.stamps && wpc == 1) hipLaunchKernelGGL((squad_chain_kernel<1, true>), dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
+    else if (sa.stamps && wpc == 2) hipLaunchKernelGGL((squad_chain_kernel<2, true>), dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
+    else if (sa.stamps) hipLaunchKernelGGL((squad_chain_kernel<3, true>), dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
     else
 #endif
     if (wpc == 1) hipLaunchKernelGGL(squad_chain_kernel<1>, dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
