@@ -415,7 +415,7 @@ def train_split_leg(dev, steps):
     leaves of the graph -- on the bf16 matrix pipe at fp32 accuracy (csrc/wgrad_group.h: operands split as they are staged); forward
     and the dgrad chain stay fp32 (latency-bound launches of 10-50 us).  Opt-in, not the `train` figure."""
     r = train_leg(dev, None, 1, 0, steps, None, precision="bf16x3", epochs=False)
-    return {"dtype": "weight gradients: bf16x3 split, f32 accumulate; forward / dgrad: f32", "ms_per_step": r["ms_per_step"],
+    return {"dtype": "weight gradients and output_proj + MSE: bf16x3 split, f32 accumulate; the rest of forward / dgrad: f32", "ms_per_step": r["ms_per_step"],
             "samples_per_s": r["samples_per_s"], "final_loss": r["final_loss"],
             "effective_tflops": r["achieved_tflops"], "effective_vs_fp32_mfma_peak": r["frac_of_fp32_mfma_peak"]}
 

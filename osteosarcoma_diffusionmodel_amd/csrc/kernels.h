@@ -20,6 +20,8 @@ hipError_t launch_input(hipStream_t s, const GemmArgs& g, const EpiInput::Args& 
 hipError_t launch_input_splitk(hipStream_t s, const GemmArgs& g, const EpiInput::Args& a, float* slabs, int slices);
 hipError_t launch_posterior(hipStream_t s, const GemmArgs& g, const EpiPosterior::Args& a);
 hipError_t launch_mse(hipStream_t s, const GemmArgs& g, const EpiMse::Args& a);
+// k_b3t.hip: precision = 1 (hipErrorInvalidValue: outside the kernel's preconditions -- run the fp32 launch)
+hipError_t launch_mse_b3t(hipStream_t s, const GemmArgs& g, const EpiMse::Args& a);
 
 // k_gn.hip / k_gn_drop.hip ------------------------------------------------------------
 // Arguments common to every GW; the wrappers copy them into EpiGnSilu<GW,DROP>::Args.

@@ -532,7 +532,10 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
     ea.dout = grads ? W.d_out : nullptr; ea.ldd = D; ea.pred = cp ? W.pred : nullptr; ea.ldp = D; ea.loss = loss_out;
     ea.inv_count = (float)(1.0 / ((double)n * (double)D));
     ea.gscale = (float)(2.0 * (double)loss_scale / ((double)n * (double)D));
-    OSD_HIP(launch_mse(s, g, ea));
+    // precision = 1: output_proj + MSE on the bf16 matrix pipe, operands split where they are staged (gemm_b3t.h)
+    hipError_t me = h->precision == 1 ? launch_mse_b3t(s, g, ea) : hipErrorInvalidValue;
+    if (me == hipErrorInvalidValue) { (void)hipGetLastError(); me = launch_mse(s, g, ea); }
+    OSD_HIP(me);
   }
   if (cp) {
     OSD_HIP(hipMemcpyAsync(h->parts_dev, loss_out, 4, hipMemcpyDeviceToDevice, s));
