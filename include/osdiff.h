@@ -96,7 +96,8 @@ int osd_set_stream(osd_handle *h, void *hip_stream);
  * with every activation in LDS, bit-identical, for architectures whose panels fit -- hidden_dims[0] = 256 = the last block's
  * width --, others fall back to 1; it runs at its full rate from 16 384 rows on; 3 the squad chain, the small-batch kernel: eight
  * workgroups per 32 patients for the whole chain, for models it decomposes ("squad_chain_supported") and batches whose squads are all
- * resident -- 3 072 rows on 256 CUs --, others run what auto would; it agrees with the other engines to fp32 rounding, not bitwise;
+ * resident -- 3 072 rows on 256 CUs --, others run what auto would; it agrees with the other engines to fp32 rounding, not bitwise
+ * ("squad_panel": its patients per panel, 0 auto = 16 up to 1 024 rows and 32 above, or 16 / 32; "last_squad_panel" reads back);
  * 0 auto: 1 from 65 536 rows on, 2 from 10 240 rows on, 3 for resident batches when "input_splitk" != 0), "dual_dgrad" / "train_ksplit" /
  * "train_input_splitk" (training-step experiments), "input_splitk" (the small-batch mode of sampling: 0 off --
  * the default: a row's result does not depend on the batch it is in, bit for bit --, -1 auto, n > 0 slices: small batches run

@@ -260,7 +260,7 @@ int refresh_derived(osd_handle* h, hipStream_t s, bool pack_in_w) {
   g.F = a.H0; g.P = a.T; g.K = a.time_dim;
   OSD_HIP(launch_linear(s, g, true, true, h->params[a.pm.tp_b], h->d_temb, a.H0, false, false));
   h->panel_wpk_valid = false;           // the LDS-resident chain repacks its fragment-ordered copies before its next run
-  h->squad_wpk_valid = false;           // ... and the squad chain its own
+  h->squad_wpk_valid[0] = h->squad_wpk_valid[1] = false;      // ... and the squad chains theirs
   h->split_valid = false;               // ... and the bf16x3 engine its weight planes
   if (!pack_in_w) {                     // a training step that reads input_proj.weight directly: the packed copies go stale and are
     h->w_packed_stale = true;           // refreshed by the next entry point that reads them (ensure_packed) or osd_load_weights
@@ -469,6 +469,11 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
     h->sampler = (int)value;
     return OSD_OK;
   }
+  if (!strcmp(name, "squad_panel")) {             // the squad chain's panel: 0 auto, 16 (chain_squad16.h) wherever its squads fit two per CU, 32 (chain_squad.h)
+    if (value != 0 && value != 16 && value != 32) { set_error("squad_panel must be 0 (auto), 16 or 32"); return OSD_EINVAL; }
+    h->squad_panel = (int)value;
+    return OSD_OK;
+  }
   if (!strcmp(name, "chain_variant")) {           // 0 auto, 1 workspace chain (chain.h), 2 LDS-resident chain (chain_panel.h) where the architecture fits
     if (value < 0 || value > 3) { set_error("chain_variant must be 0 (auto), 1 (workspace chain), 2 (LDS-resident chain) or 3 (squad chain)"); return OSD_EINVAL; }
     h->chain_variant = (int)value;
@@ -561,7 +566,7 @@ int osd_get_option(osd_handle* h, const char* name, int64_t* value) {
       {"precision", h->precision}, {"last_precision", h->last_precision}, {"split_supported", split_supported(h->arch) ? 1 : 0},
       {"chain_fallbacks", h->chain_fallbacks}, {"last_engine", h->last_engine},
       {"chain_variant", h->chain_variant}, {"last_chain_variant", h->last_chain_variant}, {"panel_chain_supported", panel_chain_supported(h) ? 1 : 0},
-      {"squad_chain_supported", squad_chain_supported(h) ? 1 : 0}};
+      {"squad_chain_supported", squad_chain_supported(h) ? 1 : 0}, {"last_squad_panel", h->last_squad_rp}, {"squad_panel", h->squad_panel}};
   for (const auto& e : tab)
     if (!strcmp(name, e.n)) { *value = e.v; return OSD_OK; }
   set_error("unknown option '%s'", name);

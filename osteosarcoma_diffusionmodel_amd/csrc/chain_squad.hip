@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <vector>
 #include "chain_squad.h"
+#include "chain_squad16.h"
 #include "handle.h"
 #include "kernels.h"
 #include "fwd.h"
@@ -23,18 +24,20 @@ struct SquadPlan {
 // Architectures the squad decomposition covers: 8 GroupNorm groups of 32 or 64 features (block widths 256 / 512), input_proj to
 // 256 features (8 feature blocks: two per wave, one per workgroup in the reduce phase), output_proj from 256, every K a
 // multiple of 128 (a wave's quarter is whole 8-k blocks of SQ_DEPTH-friendly length).
-static SquadPlan make_plan(const Arch& a) {
+// rp = patients per panel: 32 (chain_squad.h: 8-k blocks, 32-feature state tiles) or 16 (chain_squad16.h: 16-k blocks, 16-feature tiles)
+static SquadPlan make_plan(const Arch& a, int rp = SQ_RP) {
   SquadPlan p;
+  const int kblk = rp == 32 ? 8 : 16, tile = rp == 32 ? 32 : 16;
   if (!chain_supported(a)) return p;
   if (a.H0 != 256) return p;
   if ((int)a.layers.size() > SQ_MAX_LAYERS) return p;
   if (a.block_out[a.n_blocks - 1] != 256) return p;
-  p.T32 = (a.D + 31) / 32;
-  if (p.T32 < SQ_S) return p;                                  // every workgroup owns at least one state tile
+  p.T32 = (a.D + tile - 1) / tile;
+  if ((a.D + 31) / 32 < SQ_S) return p;                        // every workgroup owns at least one state tile (of either size)
   int64_t woff = 0;
   int off = 0;
   std::vector<int> buf_of_layer(a.layers.size());
-  p.h0_out = off; off += SQ_RP * a.H0;
+  p.h0_out = off; off += rp * a.H0;
   int cur = p.h0_out, cur_w = a.H0;
   for (int b = 0; b < a.n_blocks; ++b)
     for (int half = 0; half < 2; ++half) {
@@ -45,26 +48,26 @@ static SquadPlan make_plan(const Arch& a) {
       const int K = ld.K1 + ld.K2;
       if (ld.N != 256 && ld.N != 512) return p;
       if (ld.gw != ld.N / 8) return p;
-      if (ld.K1 != cur_w || K % 128 || ld.K1 % 8 || ld.K2 % 8) return p;
-      L.K8 = K / 8; L.F = ld.N; L.in0 = cur; L.n8_0 = ld.K1 / 8; L.in1 = -1;
+      if (ld.K1 != cur_w || K % 128 || ld.K1 % 16 || ld.K2 % 16) return p;
+      L.K8 = K / kblk; L.F = ld.N; L.in0 = cur; L.n8_0 = ld.K1 / kblk; L.in1 = -1;
       if (ld.K2 > 0) {
         const int sb = a.n_enc - 1 - (b - a.n_enc - 1);
         if (sb < 0 || sb >= b || a.block_out[sb] != ld.K2) return p;
         L.in1 = buf_of_layer[2 * sb + 1];
       }
-      L.out = off; off += SQ_RP * ld.N;
+      L.out = off; off += rp * ld.N;
       buf_of_layer[li] = L.out;
       p.wpk_off[li] = woff;
-      woff += (int64_t)(ld.N / 32) * L.K8 * 256;
+      woff += (int64_t)ld.N * K;
       cur = L.out; cur_w = ld.N;
     }
   p.n_layers = (int)a.layers.size();
   p.last_in = cur;
-  p.K8_out = cur_w / 8;
-  if (p.K8_out != 32) return p;                                // the operand of output_proj: 32 KB of LDS beside the K-split partials
-  p.in_off = woff; woff += (int64_t)(a.H0 / 32) * (4 * p.T32) * 256;
-  p.out_off = woff; woff += (int64_t)p.T32 * p.K8_out * 256;
-  p.bias_off = woff; woff += (int64_t)p.T32 * 32;
+  p.K8_out = cur_w / kblk;
+  if (cur_w != 256) return p;                                  // the operand of output_proj in LDS beside the K-split partials
+  p.in_off = woff; woff += (int64_t)a.H0 * p.T32 * tile;
+  p.out_off = woff; woff += (int64_t)p.T32 * tile * cur_w;
+  p.bias_off = woff; woff += (int64_t)p.T32 * tile;
   p.wpk_floats = woff;
   if (woff * 4 >= (int64_t)1 << 31) return p;                  // byte offsets into the packed weights are ints
   p.act_floats = (off + 63) / 64 * 64;
@@ -74,7 +77,7 @@ static SquadPlan make_plan(const Arch& a) {
 
 bool squad_chain_supported(const osd_handle* h) { return make_plan(h->arch).ok; }
 
-struct SquadDev { int occ[3] = {0, 0, 0}; int cus = 0; int lds = 0; bool ready = false; };      // occupancies at `lds` bytes of dynamic LDS
+struct SquadDev { int occ[3] = {0, 0, 0}; int occ16 = 0; int cus = 0; int lds = 0; bool ready = false; };      // occupancies at `lds` bytes of dynamic LDS
 static SquadDev g_squad_dev[16];
 
 template <int WPC>
@@ -95,6 +98,11 @@ static int squad_device(int device, int lds, SquadDev** out) {
     OSD_TRY(squad_occ<1>(&d.occ[0], lds));
     OSD_TRY(squad_occ<2>(&d.occ[1], lds));
     OSD_TRY(squad_occ<3>(&d.occ[2], lds));
+    {
+      const int lds16 = lds - (SQ_STAGE_FLOATS - SQ16_STAGE_FLOATS) * 4;
+      OSD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d.occ16, squad16_chain_kernel<false>, SQ_THREADS, lds16));
+      if (d.occ16 > 2) d.occ16 = 2;
+    }
     d.lds = lds;
     hipDeviceProp_t prop;
     OSD_HIP(hipGetDeviceProperties(&prop, device));
@@ -115,6 +123,18 @@ static int squad_wpc(osd_handle* h, int64_t n) {
   return 0;
 }
 
+// 16-patient panels (chain_squad16.h): when they put two workgroups of different squads on every CU at most -- up to 1 024 rows on
+// 256 CUs -- where the 32-patient squads are one workgroup per CU or less
+static bool squad_use16(osd_handle* h, int64_t n) {
+  if (h->squad_panel == 32) return false;                  // osd_set_option("squad_panel"): 0 auto, 16 wherever it fits, 32 never
+  SquadDev* d = nullptr;
+  if (squad_device(h->cfg.device, sq_lds_bytes((int)h->arch.layers.size()), &d) != OSD_OK) { (void)hipGetLastError(); return false; }
+  if (d->occ16 < 2) return false;
+  const int64_t wgs16 = (n + SQ16_RP - 1) / SQ16_RP * SQ_S, wgs32 = (n + SQ_RP - 1) / SQ_RP * SQ_S;
+  if (wgs16 > 2 * (int64_t)d->cus) return false;
+  return h->squad_panel == 16 || wgs32 <= (int64_t)d->cus;
+}
+
 // auto: chains whose squads all fit on the chip at once (3 072 rows on 256 CUs)
 bool squad_window(osd_handle* h, int64_t n) {
   if (h->chain_variant != 0 && h->chain_variant != 3) return false;
@@ -122,24 +142,55 @@ bool squad_window(osd_handle* h, int64_t n) {
   return squad_wpc(h, n) > 0;
 }
 
-static int squad_pack(osd_handle* h, hipStream_t s, const SquadPlan& p) {
+// dst[((fb * K16 + i) * 64 + lane) * 4 + e] = W[16 fb + (lane & 15)][16 i + 4 (lane >> 4) + e], zero beyond (F, K): chain_squad16.h's order
+__global__ void k_pack_fragments16(const float* __restrict__ w, int ldw, int F, int K, int nfb, int K16, float* __restrict__ dst) {
+  const long long total = (long long)nfb * K16 * 64;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long long blk = i >> 6;
+    const int i16 = (int)(blk % K16), fb = (int)(blk / K16);
+    const int f = 16 * fb + (lane & 15), k = 16 * i16 + 4 * (lane >> 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < F) {
+      const float* r = w + (size_t)f * ldw + k;
+      if (k < K) v.x = r[0];
+      if (k + 1 < K) v.y = r[1];
+      if (k + 2 < K) v.z = r[2];
+      if (k + 3 < K) v.w = r[3];
+    }
+    reinterpret_cast<float4*>(dst)[i] = v;
+  }
+}
+
+static hipError_t pack_any(hipStream_t s, int rp, const float* w, int ldw, int F, int K, int nfb, int KB, float* dst) {
+  if (rp == 32) return launch_pack_fragments(s, w, ldw, F, K, nfb, KB, dst);
+  const long long total = (long long)nfb * KB * 64;
+  const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_pack_fragments16, dim3(grid), dim3(256), 0, s, w, ldw, F, K, nfb, KB, dst);
+  return hipGetLastError();
+}
+
+// slot 0: the 32-patient kernel's copies, slot 1: the 16-patient kernel's
+static int squad_pack(osd_handle* h, hipStream_t s, const SquadPlan& p, int rp) {
   const Arch& a = h->arch;
-  if (h->squad_wpk_floats < p.wpk_floats) {
-    if (h->squad_wpk) { OSD_HIP(hipStreamSynchronize(s)); OSD_HIP(hipFree(h->squad_wpk)); h->squad_wpk = nullptr; h->squad_wpk_floats = 0; }
-    if (hipMalloc((void**)&h->squad_wpk, (size_t)p.wpk_floats * 4) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc failed"); return OSD_ENOMEM; }
-    h->squad_wpk_floats = p.wpk_floats;
+  const int slot = rp == 32 ? 0 : 1, tile = rp;
+  float*& buf = h->squad_wpk[slot];
+  if (h->squad_wpk_floats[slot] < p.wpk_floats) {
+    if (buf) { OSD_HIP(hipStreamSynchronize(s)); OSD_HIP(hipFree(buf)); buf = nullptr; h->squad_wpk_floats[slot] = 0; }
+    if (hipMalloc((void**)&buf, (size_t)p.wpk_floats * 4) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc failed"); return OSD_ENOMEM; }
+    h->squad_wpk_floats[slot] = p.wpk_floats;
   }
   for (int l = 0; l < p.n_layers; ++l) {
     const LayerDesc& ld = a.layers[l];
-    OSD_HIP(launch_pack_fragments(s, h->params[ld.w], ld.K1 + ld.K2, ld.N, ld.K1 + ld.K2, ld.N / 32, p.L[l].K8, h->squad_wpk + p.wpk_off[l]));
+    OSD_HIP(pack_any(s, rp, h->params[ld.w], ld.K1 + ld.K2, ld.N, ld.K1 + ld.K2, ld.N / tile, p.L[l].K8, buf + p.wpk_off[l]));
   }
   // input_proj: the unpadded parameter, zero beyond D
-  OSD_HIP(launch_pack_fragments(s, h->params[a.pm.in_w], a.D, a.H0, a.D, a.H0 / 32, 4 * p.T32, h->squad_wpk + p.in_off));
+  OSD_HIP(pack_any(s, rp, h->params[a.pm.in_w], a.D, a.H0, a.D, a.H0 / tile, rp == 32 ? 4 * p.T32 : p.T32, buf + p.in_off));
   const int hl = a.block_out[a.n_blocks - 1];
-  OSD_HIP(launch_pack_fragments(s, h->params[a.pm.out_w], hl, a.D, hl, p.T32, p.K8_out, h->squad_wpk + p.out_off));
-  OSD_HIP(hipMemsetAsync(h->squad_wpk + p.bias_off, 0, (size_t)p.T32 * 32 * 4, s));
-  OSD_HIP(hipMemcpyAsync(h->squad_wpk + p.bias_off, h->params[a.pm.out_b], (size_t)a.D * 4, hipMemcpyDeviceToDevice, s));
-  h->squad_wpk_valid = true;
+  OSD_HIP(pack_any(s, rp, h->params[a.pm.out_w], hl, a.D, hl, p.T32, p.K8_out, buf + p.out_off));
+  OSD_HIP(hipMemsetAsync(buf + p.bias_off, 0, (size_t)p.T32 * tile * 4, s));
+  OSD_HIP(hipMemcpyAsync(buf + p.bias_off, h->params[a.pm.out_b], (size_t)a.D * 4, hipMemcpyDeviceToDevice, s));
+  h->squad_wpk_valid[slot] = true;
   return OSD_OK;
 }
 
@@ -148,12 +199,14 @@ int squad_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_
   const Arch& a = h->arch;
   const int T = a.T, H0 = a.H0, D = a.D;
   hipStream_t s = h->stream;
-  SquadPlan p = make_plan(a);
-  if (!p.ok) { set_error("internal: the squad chain is not available for this model"); return OSD_EUNSUPPORTED; }
   const int wpc = squad_wpc(h, n);
   if (wpc < 1) { set_error("internal: %lld rows are more than the squad chain keeps resident", (long long)n); return OSD_EUNSUPPORTED; }
-  if (!h->squad_wpk_valid) OSD_TRY(squad_pack(h, s, p));
-  const int n_panels = (int)((n + SQ_RP - 1) / SQ_RP);
+  const int rp = squad_use16(h, n) ? SQ16_RP : SQ_RP;
+  const int slot = rp == 32 ? 0 : 1;
+  SquadPlan p = make_plan(a, rp);
+  if (!p.ok) { set_error("internal: the squad chain is not available for this model"); return OSD_EUNSUPPORTED; }
+  if (!h->squad_wpk_valid[slot]) OSD_TRY(squad_pack(h, s, p, rp));
+  const int n_panels = (int)((n + rp - 1) / rp);
 
   // conditioning for all rows, hoisted (as chain.hip)
   auto up64 = [](int64_t v) { return (v + 63) / 64 * 64; };
@@ -168,8 +221,8 @@ int squad_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_
   else OSD_HIP(launch_fill_randn(s, x_out, D, n, D, seed, (uint32_t)row_offset, (uint32_t)T, TAG_POSTERIOR));
 
   SquadArgs sa{};
-  const int64_t xs_stride = (int64_t)p.T32 * 4 * 256;
-  const int64_t slab_stride = (int64_t)SQ_S * H0 * SQ_RP;
+  const int64_t xs_stride = (int64_t)p.T32 * rp * rp;              // tiles of rp features x rp patients
+  const int64_t slab_stride = (int64_t)SQ_S * H0 * rp;
   OSD_TRY(chain_ensure_buf(&h->chain_ws, &h->chain_ws_floats, (int64_t)n_panels * (xs_stride + slab_stride + p.act_floats), s));
   sa.xs = h->chain_ws; sa.xs_stride = xs_stride;
   sa.slab = sa.xs + (int64_t)n_panels * xs_stride; sa.slab_stride = slab_stride;
@@ -189,9 +242,9 @@ int squad_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_
     sa.L[l] = L;
   }
   sa.n_layers = p.n_layers;
-  sa.wpk = h->squad_wpk; sa.wpk_floats = p.wpk_floats;
+  sa.wpk = h->squad_wpk[slot]; sa.wpk_floats = p.wpk_floats;
   sa.in_off = (int)p.in_off; sa.bias_in = h->params[a.pm.in_b]; sa.H0 = H0;
-  sa.out_off = (int)p.out_off; sa.bias_out = h->squad_wpk + p.bias_off;
+  sa.out_off = (int)p.out_off; sa.bias_out = h->squad_wpk[slot] + p.bias_off;
   sa.T32 = p.T32; sa.h0_out = p.h0_out; sa.last_in = p.last_in; sa.K8_out = p.K8_out;
   sa.x = x_out; sa.ldx = D; sa.D = D; sa.n = (int)n;
   sa.cproj = cw.cproj; sa.ldc = H0; sa.temb = h->d_temb; sa.ldt = H0; sa.coef = h->d_coef;
@@ -213,7 +266,7 @@ int squad_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_
   }
   SquadArgs* const host_args = static_cast<SquadArgs*>(h->squad_args_host);
   const int grid = n_panels * SQ_S;
-  const int lds = sq_lds_bytes(p.n_layers);
+  const int lds = rp == 32 ? sq_lds_bytes(p.n_layers) : sq16_lds_bytes(p.n_layers);
   int launch = 0;
   for (int done = 0; done < T; done += seg) {
     sa.t_first = T - 1 - done;
@@ -224,28 +277,33 @@ int squad_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_
     OSD_HIP(hipMemcpyAsync(const_cast<SquadArgs*>(dargs), &host_args[launch], sizeof(SquadArgs), hipMemcpyHostToDevice, s));
     ++launch;
 #ifdef OSD_DIAG
-    if (sa.stamps && wpc == 1) hipLaunchKernelGGL((squad_chain_kernel<1, true>), dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
+    if (rp == 16) hipLaunchKernelGGL(squad16_chain_kernel<false>, dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
+    else if (sa.stamps && wpc == 1) hipLaunchKernelGGL((squad_chain_kernel<1, true>), dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
     else if (sa.stamps && wpc == 2) hipLaunchKernelGGL((squad_chain_kernel<2, true>), dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
     else if (sa.stamps) hipLaunchKernelGGL((squad_chain_kernel<3, true>), dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
     else
 #endif
-    if (wpc == 1) hipLaunchKernelGGL(squad_chain_kernel<1>, dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
+    if (rp == 16) hipLaunchKernelGGL(squad16_chain_kernel<false>, dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
+    else if (wpc == 1) hipLaunchKernelGGL(squad_chain_kernel<1>, dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
     else if (wpc == 2) hipLaunchKernelGGL(squad_chain_kernel<2>, dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
     else hipLaunchKernelGGL(squad_chain_kernel<3>, dim3(grid), dim3(SQ_THREADS), lds, s, dargs);
     OSD_HIP(hipGetLastError());
   }
   h->chain_pending = true;
+  h->last_squad_rp = rp;
   h->chain_expected_ms = (double)T * 0.5 * wpc;       // measured: 0.1-0.2 ms per step; generous (chain.hip multiplies by 10 and adds 2 s)
   return OSD_OK;
 }
 
 void squad_chain_free(osd_handle* h) {
   hipError_t e = hipSuccess;
-  if (h->squad_wpk) e = hipFree(h->squad_wpk);
+  for (int i = 0; i < 2; ++i) {
+    if (h->squad_wpk[i]) e = hipFree(h->squad_wpk[i]);
+    h->squad_wpk[i] = nullptr; h->squad_wpk_floats[i] = 0; h->squad_wpk_valid[i] = false;
+  }
   if (h->squad_args_dev) e = hipFree(h->squad_args_dev);
   (void)e;
   free(h->squad_args_host);
-  h->squad_wpk = nullptr; h->squad_wpk_floats = 0; h->squad_wpk_valid = false;
   h->squad_args_dev = nullptr; h->squad_args_host = nullptr; h->squad_args_cap = 0;
 }
 

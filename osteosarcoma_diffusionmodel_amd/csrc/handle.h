@@ -161,8 +161,10 @@ struct osd_handle {
   bool panel_wpk_valid = false;      // false after anything that may have changed the parameters: repacked by the next chain
   void* panel_args_dev = nullptr; void* panel_args_host = nullptr; int panel_args_cap = 0;
   // small-batch variant (chain_squad.h / chain_squad.hip)
-  float* squad_wpk = nullptr; int64_t squad_wpk_floats = 0;
-  bool squad_wpk_valid = false;
+  float* squad_wpk[2] = {nullptr, nullptr}; int64_t squad_wpk_floats[2] = {0, 0};      // fragment-ordered weights: [0] 32-patient panels, [1] 16-patient panels
+  bool squad_wpk_valid[2] = {false, false};
+  int last_squad_rp = 0;             // patients per panel of the squad chain that ran last (osd_get_option "last_squad_panel")
+  int squad_panel = 0;               // osd_set_option("squad_panel"): 0 auto (16-patient panels up to one 32-patient workgroup per CU), 16, 32
   void* squad_args_dev = nullptr; void* squad_args_host = nullptr; int squad_args_cap = 0;
   // bf16x3 split precision (gemm_bf3.h / split.hip)
   int precision = 0;                 // osd_set_option("precision"): 0 fp32 MFMA (default; the reference's arithmetic), 1 bf16x3 split on the bf16 matrix pipe

@@ -240,6 +240,9 @@ class BiologyAwareDiffusionModel(nn.Module):
         # on auto's other choices)
         self.chain_variant: Optional[str] = None
         self.last_chain_variant: Optional[str] = None     # the one the most recent chain-kernel sample() used
+        # patients per panel of the squad chain: None (the library's choice: 16 up to one 32-patient workgroup per CU -- ~1 000 rows --, else 32), 16, 32
+        self.squad_panel: Optional[int] = None
+        self.last_squad_panel: Optional[int] = None
         self.chain_grid: Optional[int] = None             # workgroup count of the chain kernel (tests)
         self.chain_steps_per_launch: Optional[int] = None
         self.chain_stagger: Optional[int] = None
@@ -358,6 +361,9 @@ class BiologyAwareDiffusionModel(nn.Module):
         except KeyError:
             raise ValueError(f"chain_variant must be None, 'auto', 'workspace', 'panel' or 'squad', got {self.chain_variant!r}")
         L.check(L.lib().osd_set_option(eng.handle, b"chain_variant", variant))
+        if self.squad_panel not in (None, 0, 16, 32):
+            raise ValueError(f"squad_panel must be None, 16 or 32, got {self.squad_panel!r}")
+        L.check(L.lib().osd_set_option(eng.handle, b"squad_panel", int(self.squad_panel or 0)))
         try:
             prec = {None: 0, "fp32": 0, "f32": 0, "bf16x3": 1}[self.precision]
         except KeyError:
@@ -524,9 +530,10 @@ class BiologyAwareDiffusionModel(nn.Module):
         # a chain kernel ran iff the result is its own or it gave up and was re-run (the counter moved); a call the library
         # demoted up front (injected draws at D % 4 != 0 keep the guarded per-layer kernels) launched none and warns about nothing
         gave_up = counter(b"chain_fallbacks") > gave_up_before
-        self.last_chain_variant = None
+        self.last_chain_variant = self.last_squad_panel = None
         if used == 1 or gave_up:
             self.last_chain_variant = {1: "workspace", 2: "panel", 3: "squad"}.get(counter(b"last_chain_variant"))
+            self.last_squad_panel = counter(b"last_squad_panel") if self.last_chain_variant == "squad" else None
         if gave_up:
             import warnings
             warnings.warn(L.last_error() or "the reverse-chain kernel gave up; the chain was re-run on the per-layer kernels")

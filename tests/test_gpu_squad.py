@@ -36,10 +36,12 @@ def _get_option(m, name):
     return v.value
 
 
-def _squad(m, cond, n, **kw):
-    m.sampler, m.chain_variant = "chain", "squad"
+def _squad(m, cond, n, panel=None, **kw):
+    m.sampler, m.chain_variant, m.squad_panel = "chain", "squad", panel
     out, mask = m.sample(cond, n, return_mutation_mask=True, **kw)
     assert (m.last_sampler, m.last_chain_variant) == ("chain", "squad")
+    if panel:
+        assert m.last_squad_panel == panel
     return out, mask
 
 
@@ -59,9 +61,10 @@ def _masks_agree(mask, ref_mask, ref, tol):
 def test_squad_chain_vs_oracle_with_injected_draws():
     """The oracle's x_T and z injected, T = 20: 100 rows (three full panels + 4 rows) at the BASELINE dims, then the reference's real
     dims 62 / 5054 / 26 (D = 5142: D % 4 = 2, 161 state tiles -- one workgroup of each squad owns 21, the others 20, i.e. a K-split
-    left-over tile) with 45 rows."""
+    left-over tile) with 45 rows; both panel sizes (chain_squad.h: 32 patients, 32x32x2 MFMA; chain_squad16.h: 16 patients, 16x16x4)."""
     T = 20
-    for dims, n, seed in ((dict(), 100, 6), (dict(mutation_dim=62, expression_dim=5054, pathway_dim=26), 45, 3)):
+    for dims, n, seed, panel in ((dict(), 100, 6, 32), (dict(mutation_dim=62, expression_dim=5054, pathway_dim=26), 45, 3, 32),
+                                 (dict(), 100, 6, 16), (dict(mutation_dim=62, expression_dim=5054, pathway_dim=26), 45, 3, 16)):
         m = _model(T, seed=seed, **dims)
         D = m.data_dim
         gen = torch.Generator().manual_seed(11)
@@ -70,24 +73,29 @@ def test_squad_chain_vs_oracle_with_injected_draws():
         zs = torch.randn(T - 1, n, D, generator=gen)
         sd = {k: v.detach().cpu() for k, v in m.state_dict().items() if k.startswith(("condition_embed", "unet"))}
         ref = O.sample(sd, O.schedule_buffers("cosine", T), cond, x_T, lambda t: zs[T - 1 - t], 3, 128)
-        out, mask = _squad(m, cond.cuda(), n, x_T=x_T.cuda(), noise=zs.cuda())
-        assert_close(out, ref, 5e-5, atol=1e-5, what=f"squad chain vs oracle, D = {D}")
+        out, mask = _squad(m, cond.cuda(), n, panel, x_T=x_T.cuda(), noise=zs.cuda())
+        assert_close(out, ref, 5e-5, atol=1e-5, what=f"squad chain ({panel}-patient panels) vs oracle, D = {D}")
         md = m.mutation_dim
         refm = (ref[:, :md] > 0.5).float()
         assert _masks_agree(mask.cpu(), refm, ref, 5e-5 * ref.abs().max().item() + 1e-5)
 
 
-@pytest.mark.parametrize("dims,n", [
-    (dict(), 32),                                                             # one full panel
-    (dict(), 37),                                                             # ... and five rows of a second
-    (dict(), 999),                                                            # 3 x 333 (utils/generate.py's small default): one workgroup per CU
-    (dict(), 1500),                                                           # two workgroups per CU
-    (dict(), 3000),                                                           # 3 x 1000: three workgroups per CU
-    (dict(mutation_dim=62, expression_dim=5054, pathway_dim=26), 999),        # the reference's real dims
-    (dict(mutation_dim=10, expression_dim=487, pathway_dim=5), 300),          # D = 502: 16 state tiles, two per workgroup (both K-split)
-    (dict(mutation_dim=3, expression_dim=250, pathway_dim=3), 64),            # D = 256: exactly one tile per workgroup
+@pytest.mark.parametrize("dims,n,panel", [
+    (dict(), 32, 32),                                                             # one full panel
+    (dict(), 37, 32),                                                             # ... and five rows of a second
+    (dict(), 999, 32),                                                            # 3 x 333 (utils/generate.py's small default): one workgroup per CU
+    (dict(), 1500, 32),                                                           # two workgroups per CU
+    (dict(), 3000, 32),                                                           # 3 x 1000: three workgroups per CU
+    (dict(mutation_dim=62, expression_dim=5054, pathway_dim=26), 999, 32),        # the reference's real dims
+    (dict(mutation_dim=10, expression_dim=487, pathway_dim=5), 300, 32),          # D = 502: 16 state tiles, two per workgroup (both K-split)
+    (dict(mutation_dim=3, expression_dim=250, pathway_dim=3), 64, 32),            # D = 256: exactly one tile per workgroup
+    (dict(), 16, 16), (dict(), 21, 16), (dict(), 999, 16), (dict(), 1024, 16),    # 16-patient panels: one panel ... two workgroups on every CU
+    (dict(mutation_dim=62, expression_dim=5054, pathway_dim=26), 999, 16),        # 322 tiles of 16 features: 40 or 41 per workgroup
+    (dict(mutation_dim=10, expression_dim=487, pathway_dim=5), 300, 16),          # D = 502: 32 tiles, whole rounds only
+    (dict(mutation_dim=3, expression_dim=250, pathway_dim=3), 64, 16),            # D = 256: two tiles per workgroup, both K-split
+    (dict(mutation_dim=3, expression_dim=330, pathway_dim=3), 40, 16),            # D = 336: 21 tiles: 2 or 3 per workgroup
 ])
-def test_squad_chain_agrees_with_the_per_layer_kernels(dims, n):
+def test_squad_chain_agrees_with_the_per_layer_kernels(dims, n, panel):
     """Philox draws (same addressing in both engines), T = 8, row_offset != 0: chain tolerance against the per-layer kernels, masks
     equal away from the threshold, and bit equality with itself -- a second run, and the chain cut into launches of 3 steps (the
     state goes out row-major and comes back in between)."""
@@ -95,14 +103,14 @@ def test_squad_chain_agrees_with_the_per_layer_kernels(dims, n):
     m = _model(T, seed=5, **dims)
     cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(3)).cuda()
     ref, refm = _graph(m, cond, n, seed=77, row_offset=5)
-    out, mask = _squad(m, cond, n, seed=77, row_offset=5)
+    out, mask = _squad(m, cond, n, panel, seed=77, row_offset=5)
     assert torch.isfinite(out).all()
     assert_close(out, ref, 2e-5, atol=1e-6, what=f"squad chain vs per-layer kernels, n = {n}")
     assert _masks_agree(mask, refm, ref, 2e-5 * ref.abs().max().item() + 1e-6)
-    again, mask2 = _squad(m, cond, n, seed=77, row_offset=5)
+    again, mask2 = _squad(m, cond, n, panel, seed=77, row_offset=5)
     assert torch.equal(again, out) and torch.equal(mask2, mask)
     m.chain_steps_per_launch = 3
-    cut, mask3 = _squad(m, cond, n, seed=77, row_offset=5)
+    cut, mask3 = _squad(m, cond, n, panel, seed=77, row_offset=5)
     assert torch.equal(cut, out) and torch.equal(mask3, mask)
 
 
@@ -119,9 +127,11 @@ def test_auto_picks_the_squad_chain_for_small_batches_only():
     m.sample(cond[:333], 333, seed=2)                 # input_splitk = 0 (from _model)
     assert m.last_sampler == "graph"
     m.input_splitk = -1
-    for n, want in ((333, ("chain", "squad")), (3000, ("chain", "squad")), (6144, ("graph", None))):
+    for n, want, panel in ((333, ("chain", "squad"), 16), (1024, ("chain", "squad"), 16), (1025, ("chain", "squad"), 32), (3000, ("chain", "squad"), 32),
+                           (6144, ("graph", None), None)):
         m.sample(cond[:n], n, seed=2)
         assert (m.last_sampler, m.last_chain_variant) == want, n
+        assert m.last_squad_panel == panel, n          # 16-patient panels while they are at most two workgroups per CU (256 CUs: 1 024 rows)
     assert _get_option(m, "squad_chain_supported") == 1
     m.sampler = "chain"
     m.sample(cond[:333], 333, seed=2)

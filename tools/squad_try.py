@@ -26,10 +26,10 @@ for dims in (None, (62, 5054, 26), (10, 487, 5)):
         cond = torch.randn(n, 3, generator=torch.Generator().manual_seed(3)).cuda()
         m.sampler, m.chain_variant, m.input_splitk = "graph", None, 0
         ref, refm = m.sample(cond, n, return_mutation_mask=True, seed=77, row_offset=5)
-        m.sampler, m.chain_variant = "chain", "squad"
+        m.sampler, m.chain_variant, m.squad_panel = "chain", "squad", (16 if n <= 1024 else 32)
         out, mask = m.sample(cond, n, return_mutation_mask=True, seed=77, row_offset=5)
         d = (out - ref).abs().max().item()
-        print(f"dims={dims} n={n} ran={m.last_sampler}/{m.last_chain_variant} finite={bool(torch.isfinite(out).all())} "
+        print(f"dims={dims} n={n} ran={m.last_sampler}/{m.last_chain_variant}/{m.last_squad_panel} finite={bool(torch.isfinite(out).all())} "
               f"max|d|={d:.3e} of {ref.abs().max().item():.3e} mask_equal={torch.equal(mask, refm)}", flush=True)
         # injected draws
         D = ref.shape[1]
@@ -45,12 +45,12 @@ if len(sys.argv) > 1:
     n, T = int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 100
     m = model(T, (62, 5054, 26))
     cond = scenario_conditions(n, 0).cuda()
-    for variant in ("graph", "squad") * (int(sys.argv[3]) if len(sys.argv) > 3 else 2):
+    for variant in ("graph", "squad32", "squad16") * (int(sys.argv[3]) if len(sys.argv) > 3 else 2):
         if variant == "graph":
             m.sampler, m.chain_variant, m.input_splitk = "graph", None, -1
         else:
-            m.sampler, m.chain_variant = "chain", "squad"
+            m.sampler, m.chain_variant, m.squad_panel = "chain", "squad", int(variant[5:])
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = m.sample(cond, n, seed=5)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"{variant:6s} n={n} T={T}: {dt*1e3:8.1f} ms  {dt/T*1e6:7.1f} us/step  {n/(dt/T*1000):8.0f} patients/s at T=1000  [{m.last_sampler}/{m.last_chain_variant}]", flush=True)
+        print(f"{variant:7s} n={n} T={T}: {dt*1e3:8.1f} ms  {dt/T*1e6:7.1f} us/step  {n/(dt/T*1000):8.0f} patients/s at T=1000  [{m.last_sampler}/{m.last_chain_variant}/{m.last_squad_panel}]", flush=True)
