@@ -190,6 +190,7 @@ int run_trunk(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in) 
     }
     OSD_TRY(prof_mark(h, s));
   }
+  if (in.input_only) return OSD_OK;
   const float* cur = ws.h0;
   int cur_w = a.H0;
   for (int b = 0; b < a.n_blocks; ++b) {
@@ -469,6 +470,10 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
     h->sampler = (int)value;
     return OSD_OK;
   }
+  if (!strcmp(name, "train_squad")) {             // 1 (default): the trunk of a training forward pass as one launch of squads from 2 048 rows on (train_squad.h); 0: per-layer launches
+    h->train_squad = value != 0;
+    return OSD_OK;
+  }
   if (!strcmp(name, "squad_panel")) {             // the squad chain's panel: 0 auto, 16 (chain_squad16.h) wherever its squads fit two per CU, 32 (chain_squad.h)
     if (value != 0 && value != 16 && value != 32) { set_error("squad_panel must be 0 (auto), 16 or 32"); return OSD_EINVAL; }
     h->squad_panel = (int)value;
@@ -566,7 +571,7 @@ int osd_get_option(osd_handle* h, const char* name, int64_t* value) {
       {"precision", h->precision}, {"last_precision", h->last_precision}, {"split_supported", split_supported(h->arch) ? 1 : 0},
       {"chain_fallbacks", h->chain_fallbacks}, {"last_engine", h->last_engine},
       {"chain_variant", h->chain_variant}, {"last_chain_variant", h->last_chain_variant}, {"panel_chain_supported", panel_chain_supported(h) ? 1 : 0},
-      {"squad_chain_supported", squad_chain_supported(h) ? 1 : 0}, {"last_squad_panel", h->last_squad_rp}, {"squad_panel", h->squad_panel}};
+      {"squad_chain_supported", squad_chain_supported(h) ? 1 : 0}, {"last_squad_panel", h->last_squad_rp}, {"squad_panel", h->squad_panel}, {"train_squad", h->train_squad}};
   for (const auto& e : tab)
     if (!strcmp(name, e.n)) { *value = e.v; return OSD_OK; }
   set_error("unknown option '%s'", name);

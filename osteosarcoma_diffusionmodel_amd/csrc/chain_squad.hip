@@ -5,6 +5,7 @@
 #include <vector>
 #include "chain_squad.h"
 #include "chain_squad16.h"
+#include "train_squad.h"
 #include "handle.h"
 #include "kernels.h"
 #include "fwd.h"
@@ -292,6 +293,85 @@ int squad_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_
   h->chain_pending = true;
   h->last_squad_rp = rp;
   h->chain_expected_ms = (double)T * 0.5 * wpc;       // measured: 0.1-0.2 ms per step; generous (chain.hip multiplies by 10 and adds 2 s)
+  return OSD_OK;
+}
+
+// ---- the training forward trunk as one launch of squads (train_squad.h) ----------------------------------------------------------
+// every layer's weight into fragment order in ONE launch (blockIdx.y = layer): the parameters change every step
+struct PackMulti { const float* w[SQ_MAX_LAYERS]; int F[SQ_MAX_LAYERS], K[SQ_MAX_LAYERS]; long long off[SQ_MAX_LAYERS]; };
+__global__ void k_pack_fragments_multi(PackMulti pm, float* __restrict__ dst) {
+  const int l = blockIdx.y;
+  const float* __restrict__ w = pm.w[l];
+  const int F = pm.F[l], K = pm.K[l], K8 = K / 8;
+  const long long total = (long long)(F / 32) * K8 * 64;
+  float4* const out = reinterpret_cast<float4*>(dst + pm.off[l]);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long long blk = i >> 6;
+    const int i8 = (int)(blk % K8), fb = (int)(blk / K8);
+    out[i] = *reinterpret_cast<const float4*>(w + (size_t)(32 * fb + (lane & 31)) * K + 8 * i8 + 4 * (lane >> 5));
+  }
+}
+
+// floats of unit-order activations per 32-patient sub-panel (0 = the model is outside the squad decomposition) and of the
+// fragment-ordered trunk weights
+int64_t train_squad_act_floats(const Arch& a, int64_t* wpk_floats) {
+  const SquadPlan p = make_plan(a, SQ_RP);
+  if (wpk_floats) *wpk_floats = p.ok ? p.in_off : 0;
+  return p.ok ? p.act_floats : 0;
+}
+
+// Worth it from a few thousand rows on (64-patient panels: 2 048 rows = half the CUs); smaller batches keep the per-layer launches.
+bool train_squad_ok(const osd_handle* h, int64_t n) {
+  if (h->train_squad == 0 || n < 2048 || !make_plan(h->arch, SQ_RP).ok) return false;
+  for (const LayerDesc& ld : h->arch.layers)                      // 16-byte fragment loads straight from the parameters
+    if (reinterpret_cast<uintptr_t>(h->params[ld.w]) & 15) return false;
+  return true;
+}
+
+int train_squad_forward(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in, float* act_units, float* wpk, unsigned* bar_and_status,
+                        int64_t panels, float* loss_poison) {
+  const Arch& a = h->arch;
+  const SquadPlan p = make_plan(a, SQ_RP);
+  if (!p.ok) { set_error("internal: the squad forward is not available for this model"); return OSD_EUNSUPPORTED; }
+  static bool attr_done = false;
+  if (!attr_done) {
+    OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(train_squad_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ts_lds_bytes(SQ_MAX_LAYERS)));
+    attr_done = true;
+  }
+  TrainSquadArgs ta{};
+  PackMulti pm{};
+  const bool drop = in.train && h->cfg.dropout_p > 0.f;
+  for (int b = 0; b < a.n_blocks; ++b)
+    for (int half = 0; half < 2; ++half) {
+      const int li = 2 * b + half;
+      const LayerDesc& ld = a.layers[li];
+      TrainSquadLayer& L = ta.L[li];
+      L.w_off = (int)p.wpk_off[li]; L.K = ld.K1 + ld.K2; L.F = ld.N;
+      pm.w[li] = h->params[ld.w]; pm.F[li] = ld.N; pm.K[li] = ld.K1 + ld.K2; pm.off[li] = p.wpk_off[li];
+      L.in0 = p.L[li].in0; L.n8_0 = p.L[li].n8_0; L.in1 = p.L[li].in1; L.out = p.L[li].out;
+      L.bias = h->params[ld.b]; L.gamma = h->params[ld.gamma]; L.beta = h->params[ld.beta];
+      L.y = half == 0 ? ws.mid[b] : ws.out[b]; L.ldy = ld.N;
+      L.z = in.save ? (half == 0 ? ws.z1[b] : ws.z2[b]) : nullptr;
+      L.stats = in.save ? (half == 0 ? ws.st1[b] : ws.st2[b]) : nullptr;
+      L.drop_mode = (half == 0 && drop) ? (in.masks ? 1 : 2) : 0;
+      L.mask = (half == 0 && drop && in.masks) ? in.masks[b] : nullptr; L.ldm = ld.N;
+      L.tag = TAG_DROPOUT + (uint32_t)b;
+    }
+  ta.n_layers = p.n_layers;
+  ta.wpk = wpk; ta.wpk_floats = p.in_off;            // the trunk weights come first in the plan's order
+  hipLaunchKernelGGL(k_pack_fragments_multi, dim3(128, (unsigned)p.n_layers), dim3(256), 0, s, pm, wpk);
+  OSD_HIP(hipGetLastError());
+  ta.h0 = ws.h0; ta.ldh = a.H0; ta.h0_out = p.h0_out;
+  ta.n = (int)in.n;
+  ta.act = act_units; ta.act_stride = p.act_floats;
+  ta.bar = bar_and_status; ta.status = bar_and_status + panels * 16;
+  ta.loss_poison = loss_poison;
+  ta.spin_budget = std::min<unsigned long long>(h->chain_spin_budget, 20000000ull);      // <= 0.2 s: a training step has no fallback to wait for
+  ta.keep_scale = (float)(1.0 / (1.0 - (double)h->cfg.dropout_p)); ta.p_drop = h->cfg.dropout_p;
+  ta.seed = in.seed; ta.row_offset = in.row_offset; ta.step = in.drop_step;
+  hipLaunchKernelGGL(train_squad_fwd_kernel, dim3((unsigned)(panels * SQ_S)), dim3(SQ_THREADS), ts_lds_bytes(p.n_layers), s, ta);
+  OSD_HIP(hipGetLastError());
   return OSD_OK;
 }
 

@@ -17,6 +17,7 @@ struct TrunkIn {
   int kx;                        // K extent of input_proj: 0 = D; Dp when x is the padded chain state (handle.h)
   const int* t_index;            // per-row t (training) or null
   const int* t_dev; int t_imm;   // shared t: device counter (sampling chain) or immediate
+  bool input_only;               // stop after input_proj (the blocks run elsewhere: train_squad.h)
   bool train;                    // dropout active
   bool save;                     // keep pre-norm activations + GroupNorm statistics for backward
   const float* const* masks;     // injected keep-masks per block, or null -> Philox
@@ -57,6 +58,11 @@ bool squad_window(osd_handle* h, int64_t n);
 int squad_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_T, const float* noises, uint64_t seed, int64_t row_offset,
                     float* x_out, float* mut_mask_out);
 void squad_chain_free(osd_handle* h);
+// train_squad.h (host side in chain_squad.hip): the training forward trunk as one launch of squads
+int64_t train_squad_act_floats(const Arch& a, int64_t* wpk_floats);
+bool train_squad_ok(const osd_handle* h, int64_t n);
+int train_squad_forward(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in, float* act_units, float* wpk, unsigned* bar_and_status,
+                        int64_t panels, float* loss_poison);
 // wgrad_group.hip
 struct WgPending;
 int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::vector<WgPending>& pend, float* slabs, int64_t slab_floats,

@@ -28,6 +28,10 @@ struct TrainWs {
   float* partials;   // gn backward column partials
   float* slabs;      // split-K wgrad partial tiles
   int64_t slab_floats;
+  float* sq_act;     // train_squad.h: unit-order activations, per 32-patient sub-panel (null: model outside the squad decomposition)
+  float* sq_wpk;     // ... this step's fragment-ordered trunk weights
+  unsigned* sq_bar;  // ... its barrier counters [panels][16] + the status word
+  int64_t sq_panels;
   // constraint losses (only carved when configured)
   float *pred, *g_x0;
   ConsWs cw;
@@ -59,6 +63,14 @@ static int64_t carve_train(const Arch& a, float* base, int64_t n, const ConsPlan
   w->partials = take((int64_t)GN_BWD_MAX_BLOCKS * 3 * cmax);
   w->slab_floats = 16 * 1024 * 1024;      // 64 MB of split-K slabs
   w->slabs = take(w->slab_floats);
+  {
+    int64_t wf = 0;
+    const int64_t af = train_squad_act_floats(a, &wf);
+    w->sq_panels = (n + 63) / 64;
+    w->sq_act = af ? take(2 * w->sq_panels * af) : nullptr;
+    w->sq_wpk = af ? take(wf) : nullptr;
+    w->sq_bar = af ? (unsigned*)take(w->sq_panels * 16 + 16) : nullptr;      // barrier counters | status word
+  }
   w->pred = w->g_x0 = w->x0_mix = nullptr;
   if (cp) {
     w->pred = take(n * a.D); w->g_x0 = take(n * a.D); w->x0_mix = take(n * a.D);
@@ -487,6 +499,7 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   {
     auto add = [&](float* p, int64_t c) { zl.ptr[zl.n] = p; zl.count[zl.n] = c; ++zl.n; };
     add(loss_out, 1);
+    if (w.sq_bar && train_squad_ok(h, n)) add(reinterpret_cast<float*>(w.sq_bar), w.sq_panels * 16 + 16);      // the squads' barrier counters + status word
     if (cp) add(h->parts_dev, 3);
     if (cp && grads) add(w.g_x0, n * (int64_t)D);
     if (grads) add_backward_zeros(a, w, grads, &zl);
@@ -524,7 +537,13 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   // input_proj at the training batch: 256 output tiles of 63 sequential K steps, one workgroup per CU -- optionally K in slices
   // over more workgroups (k_fused.hip: partial tiles to slabs, then sum + epilogue); the slab workspace is idle during forward
   if (split_in) { in.in_slabs = W.slabs; in.in_slices = h->train_input_splitk; }
-  OSD_TRY(run_trunk(h, s, W.f, in));
+  if (W.sq_act && train_squad_ok(h, n)) {
+    in.input_only = true;
+    OSD_TRY(run_trunk(h, s, W.f, in));
+    OSD_TRY(train_squad_forward(h, s, W.f, in, W.sq_act, W.sq_wpk, W.sq_bar, W.sq_panels, loss_out));
+  } else {
+    OSD_TRY(run_trunk(h, s, W.f, in));
+  }
   {
     GemmArgs g = output_proj_args(h, W.f, n);
     EpiMse::Args ea{};
