@@ -99,7 +99,9 @@ int osd_set_stream(osd_handle *h, void *hip_stream);
  * resident -- 3 072 rows on 256 CUs --, others run what auto would; it agrees with the other engines to fp32 rounding, not bitwise
  * ("squad_panel": its patients per panel, 0 auto = 16 up to 1 024 rows and 32 above, or 16 / 32; "last_squad_panel" reads back);
  * 0 auto: 1 from 65 536 rows on, 2 from 10 240 rows on, 3 for resident batches when "input_splitk" != 0), "dual_dgrad" / "train_ksplit" /
- * "train_input_splitk" (training-step experiments), "input_splitk" (the small-batch mode of sampling: 0 off --
+ * "train_input_splitk" (training-step experiments), "train_squad" (1, the default: from 2 048 rows on the ten
+ * Linear+GroupNorm+SiLU layers of a training forward pass run as one launch of squads, csrc/train_squad.h; 0: per-layer launches),
+ * "input_splitk" (the small-batch mode of sampling: 0 off --
  * the default: a row's result does not depend on the batch it is in, bit for bit --, -1 auto, n > 0 slices: small batches run
  * input_proj and the deep layers split over K, or, where chain_variant 3 applies, the squad chain; another fp32 summation order,
  * chain tolerance against the default).  Auto sampler: the chain kernel when the batch has at least as many 128-row tiles as the device

@@ -260,6 +260,9 @@ class BiologyAwareDiffusionModel(nn.Module):
         self.precision: Optional[str] = None
         self.last_precision: Optional[str] = None         # what the most recent predict_noise / p_sample / sample computed in
         self.train_streams: Optional[int] = None      # 1 = whole backward on one stream, 2 (library default) = weight gradients on a side stream
+        # the ten Linear+GroupNorm+SiLU layers of a training forward pass as one launch of squads (csrc/train_squad.h) from 2 048 rows on:
+        # None / True (library default) or False (per-layer launches)
+        self.train_squad: Optional[bool] = None
         # optional constraint losses (set_constraints); None = the reference's eps-MSE only
         self._constraints = None
         self._constraints_version = 0
@@ -351,6 +354,8 @@ class BiologyAwareDiffusionModel(nn.Module):
             L.check(L.lib().osd_set_option(eng.handle, b"n_streams", int(self.sample_streams)))
         if self.train_streams:
             L.check(L.lib().osd_set_option(eng.handle, b"train_streams", int(self.train_streams)))
+        if self.train_squad is not None:
+            L.check(L.lib().osd_set_option(eng.handle, b"train_squad", int(bool(self.train_squad))))
         try:
             mode = {"auto": 0, "chain": 1, "graph": 2, "layers": 2}[self.sampler]
         except KeyError:

@@ -155,6 +155,28 @@ def test_config2_weight_gradients_on_the_bf16_pipe_vs_oracle(mask_mode):
             assert_close(p.grad.cpu(), ref["grads"][k], GRAD_RTOL, atol=1e-9, what=f"grad {k} (bf16x3 weight gradients, pass {rep})")
 
 
+@pytest.mark.parametrize("n", [4096, 2100])
+def test_config2_forward_trunk_as_one_squad_launch_vs_per_layer_launches(n):
+    """csrc/train_squad.h: from 2 048 rows on the ten Linear+GroupNorm+SiLU(+Dropout) layers of a training forward pass run as ONE
+    launch of squads (eight workgroups per 64 patients; two K-halves per output: another fp32 summation order).  The test above
+    holds it to the oracle at B = 4096; here it is compared with the per-layer launches it replaces (``train_squad = False``) on
+    the same inputs and the same Philox dropout draws: loss and all 52 gradients, at the full batch and at 2 100 rows (a last panel
+    of 52 patients, below one workgroup per CU)."""
+    sd, x, cond, t, noise, _ = _inputs()
+    kw = dict(t=t[:n].cuda(), noise=noise[:n].cuda(), seed=SEED)
+    out = {}
+    for squad in (False, True):
+        m, _ = _model(2)
+        m.train_squad = squad
+        loss = m(x[:n].cuda(), cond[:n].cuda(), **kw)
+        loss.backward()
+        out[squad] = (loss.item(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()})
+    assert_close(out[True][0], out[False][0], 2e-6, what="loss, squad forward vs per-layer launches")
+    assert out[True][0] != out[False][0] or n < 0          # it really is another summation order (equal losses would mean the switch did nothing)
+    for k in out[True][1]:
+        assert_close(out[True][1][k], out[False][1][k], GRAD_RTOL, atol=1e-9, what=f"grad {k}, squad forward vs per-layer launches")
+
+
 def test_full_shape_trained_weights_chain_vs_oracle():
     """SURVEY section 8d, 'briefly CPU-trained checkpoint' at the BASELINE shape: the oracle trains the D = 2000 model
     for 100 AdamW steps on low-rank structured synthetic patients, then the device runs a T = 200 reverse chain on 32
