@@ -70,6 +70,9 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void train_squad_fwd_kernel(const Tr
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
+  // (Tried: a start offset of 6-12 us for every second / fourth / ... / 64th panel, so that the two workgroups of a CU are not in the
+  // same phase: 169-176 us for the launch at 4 096 rows against 172 -- whatever keeps two workgroups per CU at 1.65 x the time of
+  // one (103 us at 2 048 rows), it is not lockstep.)
   // (Tried: squads of ONE XCD -- members blockIdx % 8 equal, placement checked through XCC_ID behind an agent-scope first barrier --
   // handing over through that XCD's L2 with plain loads / stores and an L2-atomic barrier: 0.886 vs 0.882 ms per step.  The
   // memory-side hand-off is not what bounds this launch; removed.)
