@@ -172,9 +172,10 @@ def test_config2_forward_trunk_as_one_squad_launch_vs_per_layer_launches(n):
         loss.backward()
         out[squad] = (loss.item(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()})
     assert_close(out[True][0], out[False][0], 2e-6, what="loss, squad forward vs per-layer launches")
-    assert out[True][0] != out[False][0] or n < 0          # it really is another summation order (equal losses would mean the switch did nothing)
     for k in out[True][1]:
         assert_close(out[True][1][k], out[False][1][k], GRAD_RTOL, atol=1e-9, what=f"grad {k}, squad forward vs per-layer launches")
+    # it really is another summation order (bit-equal gradients everywhere would mean the switch did nothing)
+    assert any(not torch.equal(out[True][1][k], out[False][1][k]) for k in out[True][1])
 
 
 def test_full_shape_trained_weights_chain_vs_oracle():
