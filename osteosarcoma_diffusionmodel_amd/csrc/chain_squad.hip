@@ -370,6 +370,7 @@ int train_squad_forward(osd_handle* h, hipStream_t s, const FwdWs& ws, const Tru
   ta.spin_budget = std::min<unsigned long long>(h->chain_spin_budget, 20000000ull);      // <= 0.2 s: a training step has no fallback to wait for
   ta.keep_scale = (float)(1.0 / (1.0 - (double)h->cfg.dropout_p)); ta.p_drop = h->cfg.dropout_p;
   ta.seed = in.seed; ta.row_offset = in.row_offset; ta.step = in.drop_step;
+  ta.stamps = h->chain_stamps;                       // diagnostic builds (osd_dbg_chain_stamps), else null
   hipLaunchKernelGGL(train_squad_fwd_kernel, dim3((unsigned)(panels * SQ_S)), dim3(SQ_THREADS), ts_lds_bytes(p.n_layers), s, ta);
   OSD_HIP(hipGetLastError());
   return OSD_OK;

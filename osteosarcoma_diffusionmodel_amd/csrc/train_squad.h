@@ -54,6 +54,7 @@ struct TrainSquadArgs {
   unsigned long long spin_budget;
   float keep_scale, p_drop;
   uint64_t seed; uint32_t row_offset; uint32_t step;
+  unsigned long long* stamps;                // diagnostic (null in production): per wave 8 cycle counters (tools/train_squad_stamps.py)
 };
 
 // lane (l31, h) of a weight fragment: W[f0 + l31][8 i + 4 h .. + 3]
@@ -82,6 +83,12 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void train_squad_fwd_kernel(const Tr
   unsigned* const bar = a.bar + (size_t)panel * 16;
   unsigned nb = 0;
   const int l16 = 16 * lane;
+  unsigned long long cyc[6] = {0, 0, 0, 0, 0, 0};      // K loops | partials -> LDS + barrier | epilogue | arrive .. released | h0 units | whole kernel
+  const bool stamp = a.stamps != nullptr;
+  auto now = [&]() -> unsigned long long { return stamp ? __builtin_amdgcn_s_memtime() : 0ull; };
+  const unsigned long long c_start = now();
+  unsigned long long tc = c_start, tn;
+#define TS_STAMP(i) do { if (stamp) { asm volatile("s_nop 0" ::: "memory"); tn = now(); cyc[i] += tn - tc; tc = tn; } } while (0)
   // unit-order regions of the two sub-panels
   const __amdgpu_buffer_rsrc_t r_act0 = sq_rsrc(a.act + (size_t)(2 * panel) * a.act_stride, a.act_stride);
   const __amdgpu_buffer_rsrc_t r_act1 = sq_rsrc(a.act + (size_t)(2 * panel + 1) * a.act_stride, a.act_stride);
@@ -135,7 +142,9 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void train_squad_fwd_kernel(const Tr
     auto la = [&](int fb, int i) -> v4f { return sq_ld(r_w, l16, wl + (fb * K8 + i) * 1024); };
     if (L.F == 512) sq_prime_a<2, TS_DEPTH>(aq, L.K / 16, la); else sq_prime_a<1, TS_DEPTH>(aq, L.K / 16, la);
   };
+  TS_STAMP(4);
   if (!squad_sync([&] { prime_layer(0); })) return;
+  TS_STAMP(3);
 
   // a layer's row-major outputs of this thread, stored after the arrive: [sub-panel][32-feature block]
   float4 zq[2][2], yq[2][2];
@@ -163,6 +172,7 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void train_squad_fwd_kernel(const Tr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[fb][0][r] = 0.f;
       sq_kloop<NFB, TS_DEPTH>(acc, aq, n8h, la, lb);        // aq was primed behind the previous barrier's arrive
+      TS_STAMP(0);
       // partial accumulators -> LDS [K-half][sub-panel][patient][feature (+4)]
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb)
@@ -171,6 +181,7 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void train_squad_fwd_kernel(const Tr
           *reinterpret_cast<float4*>(stage + ((kh * 2 + rb) * 32 + l31) * LDP + 32 * fb + 8 * q + 4 * h) =
               make_float4(acc[fb][0][4 * q], acc[fb][0][4 * q + 1], acc[fb][0][4 * q + 2], acc[fb][0][4 * q + 3]);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      TS_STAMP(1);
       // epilogue: 8 threads per patient, two passes (sub-panels); thread (erow, c): features 32 j + 4 c .. + 3 of the group
       const float* pl = prm + l * SQ_PRM;
       const int erow = tid >> 3, c = tid & 7, f0 = 4 * c;
@@ -247,11 +258,19 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void train_squad_fwd_kernel(const Tr
         }
       }
     };
+    TS_STAMP(2);
     if (l + 1 < a.n_layers) {
       if (!squad_sync([&] { row_major(); prime_layer(l + 1); })) return;
+      TS_STAMP(3);
     } else {
       row_major();
     }
+  }
+#undef TS_STAMP
+  if (stamp && lane == 0) {
+    unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+    for (int i = 0; i < 5; ++i) o[i] = cyc[i];
+    o[5] = __builtin_amdgcn_s_memtime() - c_start;
   }
 }
 
