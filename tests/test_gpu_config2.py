@@ -178,6 +178,24 @@ def test_config2_forward_trunk_as_one_squad_launch_vs_per_layer_launches(n):
     assert any(not torch.equal(out[True][1][k], out[False][1][k]) for k in out[True][1])
 
 
+def test_config2_squad_forward_that_cannot_finish_poisons_the_loss():
+    """A training step has no second engine to fall back to inside the call.  A squad whose barrier runs into the spin budget (here:
+    one tick) leaves, raises the status word and writes NaN into the loss accumulator: the step's loss is NaN -- visible to
+    `Trainer` at its `loss.item()` -- instead of a finite number computed from half-written activations.  With the default
+    budget the same call is finite again."""
+    sd, x, cond, t, noise, _ = _inputs()
+    m, _ = _model(2)
+    kw = dict(t=t.cuda(), noise=noise.cuda(), seed=SEED)
+    m.chain_spin_budget = 1
+    with torch.no_grad():
+        bad = m(x.cuda(), cond.cuda(), **kw)
+    assert torch.isnan(bad).item()
+    m.chain_spin_budget = 500_000_000
+    with torch.no_grad():
+        good = m(x.cuda(), cond.cuda(), **kw)
+    assert torch.isfinite(good).item()
+
+
 def test_full_shape_trained_weights_chain_vs_oracle():
     """SURVEY section 8d, 'briefly CPU-trained checkpoint' at the BASELINE shape: the oracle trains the D = 2000 model
     for 100 AdamW steps on low-rank structured synthetic patients, then the device runs a T = 200 reverse chain on 32
