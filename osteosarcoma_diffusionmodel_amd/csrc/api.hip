@@ -471,7 +471,8 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
     return OSD_OK;
   }
   if (!strcmp(name, "train_squad")) {             // 1 (default): the trunk of a training forward pass as one launch of squads from 2 048 rows on (train_squad.h); 0: per-layer launches
-    h->train_squad = value != 0;
+    if (value < 0 || value > 2) { set_error("train_squad must be 0 (per-layer launches), 1 (forward trunk as squads) or 2 (forward and the dgrad chain)"); return OSD_EINVAL; }
+    h->train_squad = (int)value;
     return OSD_OK;
   }
   if (!strcmp(name, "squad_panel")) {             // the squad chain's panel: 0 auto, 16 (chain_squad16.h) wherever its squads fit two per CU, 32 (chain_squad.h)

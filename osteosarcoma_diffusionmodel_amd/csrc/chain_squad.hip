@@ -6,6 +6,7 @@
 #include "chain_squad.h"
 #include "chain_squad16.h"
 #include "train_squad.h"
+#include "train_squad_bwd.h"
 #include "handle.h"
 #include "kernels.h"
 #include "fwd.h"
@@ -372,6 +373,108 @@ int train_squad_forward(osd_handle* h, hipStream_t s, const FwdWs& ws, const Tru
   ta.seed = in.seed; ta.row_offset = in.row_offset; ta.step = in.drop_step;
   ta.stamps = h->chain_stamps;                       // diagnostic builds (osd_dbg_chain_stamps), else null
   hipLaunchKernelGGL(train_squad_fwd_kernel, dim3((unsigned)(panels * SQ_S)), dim3(SQ_THREADS), ts_lds_bytes(p.n_layers), s, ta);
+  OSD_HIP(hipGetLastError());
+  return OSD_OK;
+}
+
+// ---- the backward pass's dgrad chain as one launch of squads (train_squad_bwd.h) --------------------------------------------------
+// fragment order of W^T for a block of columns: dst[((fb * K8 + i) * 64 + lane) * 4 + e] = W[8 i + 4 (lane >> 5) + e][c0 + 32 fb + (lane & 31)]
+struct PackMultiT { const float* w[2 * SQ_MAX_LAYERS]; int ldw[2 * SQ_MAX_LAYERS], c0[2 * SQ_MAX_LAYERS], F[2 * SQ_MAX_LAYERS], K[2 * SQ_MAX_LAYERS]; long long off[2 * SQ_MAX_LAYERS]; };
+__global__ void k_pack_fragments_multi_t(PackMultiT pm, float* __restrict__ dst) {
+  const int l = blockIdx.y;
+  const float* __restrict__ w = pm.w[l];
+  const int ldw = pm.ldw[l], c0 = pm.c0[l], F = pm.F[l], K8 = pm.K[l] / 8;
+  const long long total = (long long)(F / 32) * K8 * 64;
+  float4* const out = reinterpret_cast<float4*>(dst + pm.off[l]);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long long blk = i >> 6;
+    const int i8 = (int)(blk % K8), fb = (int)(blk / K8);
+    const float* r = w + (size_t)(8 * i8 + 4 * (lane >> 5)) * ldw + c0 + 32 * fb + (lane & 31);
+    out[i] = make_float4(r[0], r[ldw], r[2 * (size_t)ldw], r[3 * (size_t)ldw]);
+  }
+}
+
+int64_t train_squad_bwd_wpk_floats(const Arch& a) {
+  int64_t f = 0;
+  for (const LayerDesc& ld : a.layers) f += (int64_t)ld.N * (ld.K1 + ld.K2);
+  return f;
+}
+
+int train_squad_backward(osd_handle* h, hipStream_t s, const FwdWs& f, const TrainSquadBwdBufs& B, int64_t n, float* gact_units, float* wpk,
+                         unsigned* bar_and_status, int64_t panels, float* loss_poison) {
+  const Arch& a = h->arch;
+  const SquadPlan p = make_plan(a, SQ_RP);
+  if (!p.ok) { set_error("internal: the squad backward is not available for this model"); return OSD_EUNSUPPORTED; }
+  static bool attr_done = false;
+  if (!attr_done) {
+    OSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(train_squad_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ts_lds_bytes(SQ_MAX_LAYERS)));
+    attr_done = true;
+  }
+  TrainSquadBwdArgs ta{};
+  PackMultiT pm{};
+  int np = 0, npk = 0;
+  long long woff = 0;
+  auto pack = [&](const float* w, int ldw, int c0, int F, int K) -> int {
+    pm.w[npk] = w; pm.ldw[npk] = ldw; pm.c0[npk] = c0; pm.F[npk] = F; pm.K[npk] = K; pm.off[npk] = woff; ++npk;
+    const int off = (int)woff;
+    woff += (long long)F * K;
+    return off;
+  };
+  for (int b = a.n_blocks - 1; b >= 0; --b) {
+    const LayerDesc& l1 = a.layers[2 * b];
+    const LayerDesc& l2 = a.layers[2 * b + 1];
+    const int C = l1.N, Kt = l1.K1 + l1.K2;
+    {   // through the block's second Linear into its first layer (dropout sits behind that one)
+      TrainSquadBwdPhase& P = ta.P[np++];
+      P = TrainSquadBwdPhase{};
+      P.w_off = pack(h->params[l2.w], C, 0, C, C); P.K = C; P.F = C;
+      P.in = p.L[2 * b + 1].out; P.out = p.L[2 * b].out; P.prm = 2 * b;
+      P.z = f.z1[b]; P.stats = f.st1[b]; P.gy = B.g_mid[b]; P.gz = B.g_z1[b]; P.accumulate = 0;
+      P.drop_mode = B.drop ? (B.masks ? 1 : 2) : 0; P.mask = (B.drop && B.masks) ? B.masks[b] : nullptr; P.ldm = C; P.tag = TAG_DROPOUT + (uint32_t)b;
+    }
+    if (b == 0) {                 // into h0: no GroupNorm below -- a plain phase
+      TrainSquadBwdPhase& P = ta.P[np++];
+      P = TrainSquadBwdPhase{};
+      P.w_off = pack(h->params[l1.w], Kt, 0, l1.K1, C); P.K = C; P.F = l1.K1;
+      P.in = p.L[0].out; P.out = p.h0_out; P.prm = 0; P.plain = 1; P.gz = B.g_h0;
+      break;
+    }
+    {   // through the block's first Linear into the layer that produced its main input; the skip columns ride along
+      const LayerDesc& lp = a.layers[2 * (b - 1) + 1];
+      TrainSquadBwdPhase& P = ta.P[np++];
+      P = TrainSquadBwdPhase{};
+      P.w_off = pack(h->params[l1.w], Kt, 0, l1.K1, C); P.K = C; P.F = l1.K1;
+      P.in = p.L[2 * b].out; P.out = p.L[2 * (b - 1) + 1].out; P.prm = 2 * (b - 1) + 1;
+      P.z = f.z2[b - 1]; P.stats = f.st2[b - 1]; P.gy = B.g_out[b - 1]; P.gz = B.g_z2[b - 1];
+      P.accumulate = (b - 1 < a.n_enc) ? 1 : 0;
+      P.drop_mode = 0;
+      if (l1.K2 > 0) {
+        const int skip_block = a.n_enc - 1 - (b - a.n_enc - 1);
+        P.skip_w_off = pack(h->params[l1.w], Kt, l1.K1, l1.K2, C); P.skip_F = l1.K2; P.skip_out = B.g_out[skip_block];
+      }
+      (void)lp;
+    }
+  }
+  ta.n_phases = np;
+  ta.n_layers = p.n_layers;
+  for (int li = 0; li < p.n_layers; ++li) {
+    const LayerDesc& ld = a.layers[li];
+    ta.gamma[li] = h->params[ld.gamma]; ta.beta[li] = h->params[ld.beta]; ta.width[li] = ld.N;
+  }
+  ta.wpk = wpk; ta.wpk_floats = woff;
+  const int last = a.n_blocks - 1;
+  ta.gz_top = B.g_z2[last]; ta.top_F = a.block_out[last]; ta.top_out = p.L[2 * last + 1].out;
+  ta.n = (int)n;
+  ta.act = gact_units; ta.act_stride = p.act_floats;
+  ta.bar = bar_and_status; ta.status = bar_and_status + panels * 16;
+  ta.loss_poison = loss_poison;
+  ta.spin_budget = std::min<unsigned long long>(h->chain_spin_budget, 20000000ull);
+  ta.keep_scale = (float)(1.0 / (1.0 - (double)h->cfg.dropout_p)); ta.p_drop = h->cfg.dropout_p;
+  ta.seed = B.seed; ta.row_offset = B.row_offset; ta.step = 0;
+  hipLaunchKernelGGL(k_pack_fragments_multi_t, dim3(64, (unsigned)npk), dim3(256), 0, s, pm, wpk);
+  OSD_HIP(hipGetLastError());
+  hipLaunchKernelGGL(train_squad_bwd_kernel, dim3((unsigned)(panels * SQ_S)), dim3(SQ_THREADS), ts_lds_bytes(p.n_layers), s, ta);
   OSD_HIP(hipGetLastError());
   return OSD_OK;
 }

@@ -61,6 +61,15 @@ void squad_chain_free(osd_handle* h);
 // train_squad.h (host side in chain_squad.hip): the training forward trunk as one launch of squads
 int64_t train_squad_act_floats(const Arch& a, int64_t* wpk_floats);
 bool train_squad_ok(const osd_handle* h, int64_t n);
+// train_squad_bwd.h: the dgrad chain (single-GPU steps, fused GroupNorm backward) as one launch of squads
+struct TrainSquadBwdBufs {
+  float* const* g_out; float* const* g_z2; float* const* g_mid; float* const* g_z1;      // per block, row-major (train.hip: TrainWs)
+  float* g_h0;                   // dL/dh0 [n][H0]
+  const float* const* masks; bool drop; uint64_t seed; uint32_t row_offset;
+};
+int64_t train_squad_bwd_wpk_floats(const Arch& a);
+int train_squad_backward(osd_handle* h, hipStream_t s, const FwdWs& f, const TrainSquadBwdBufs& B, int64_t n, float* gact_units, float* wpk,
+                         unsigned* bar_and_status, int64_t panels, float* loss_poison);
 int train_squad_forward(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in, float* act_units, float* wpk, unsigned* bar_and_status,
                         int64_t panels, float* loss_poison);
 // wgrad_group.hip

@@ -164,7 +164,7 @@ struct osd_handle {
   float* squad_wpk[2] = {nullptr, nullptr}; int64_t squad_wpk_floats[2] = {0, 0};      // fragment-ordered weights: [0] 32-patient panels, [1] 16-patient panels
   bool squad_wpk_valid[2] = {false, false};
   int last_squad_rp = 0;             // patients per panel of the squad chain that ran last (osd_get_option "last_squad_panel")
-  int train_squad = 1;               // osd_set_option("train_squad"): the training forward trunk as one launch of squads (train_squad.h) from 2 048 rows on
+  int train_squad = 2;               // osd_set_option("train_squad"): the training forward trunk as one launch of squads (train_squad.h) from 2 048 rows on
   int squad_panel = 0;               // osd_set_option("squad_panel"): 0 auto (16-patient panels up to one 32-patient workgroup per CU), 16, 32
   void* squad_args_dev = nullptr; void* squad_args_host = nullptr; int squad_args_cap = 0;
   // bf16x3 split precision (gemm_bf3.h / split.hip)

@@ -30,6 +30,9 @@ struct TrainWs {
   int64_t slab_floats;
   float* sq_act;     // train_squad.h: unit-order activations, per 32-patient sub-panel (null: model outside the squad decomposition)
   float* sq_wpk;     // ... this step's fragment-ordered trunk weights
+  float* sq_gact;    // train_squad_bwd.h: unit-order gradients, same geometry as sq_act
+  float* sq_wpk_t;   // ... this step's fragment-ordered transposed weights
+  unsigned* sq_bar2; // ... its barrier counters + status word
   unsigned* sq_bar;  // ... its barrier counters [panels][16] + the status word
   int64_t sq_panels;
   // constraint losses (only carved when configured)
@@ -70,6 +73,9 @@ static int64_t carve_train(const Arch& a, float* base, int64_t n, const ConsPlan
     w->sq_act = af ? take(2 * w->sq_panels * af) : nullptr;
     w->sq_wpk = af ? take(wf) : nullptr;
     w->sq_bar = af ? (unsigned*)take(w->sq_panels * 16 + 16) : nullptr;      // barrier counters | status word
+    w->sq_gact = af ? take(2 * w->sq_panels * af) : nullptr;
+    w->sq_wpk_t = af ? take(train_squad_bwd_wpk_floats(a)) : nullptr;
+    w->sq_bar2 = af ? (unsigned*)take(w->sq_panels * 16 + 16) : nullptr;
   }
   w->pred = w->g_x0 = w->x0_mix = nullptr;
   if (cp) {
@@ -174,7 +180,7 @@ static int side_stream(osd_handle* h, hipStream_t* out) {
 // activations a training-mode forward left in W.
 static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* x_t, int x_ld, const int* t_idx, const float* cond, int64_t n,
                          const float* d_out, bool train, const float* const* masks, uint64_t seed, uint32_t roff, float* const* grads,
-                         float* dx_t, void* const* events) {
+                         float* dx_t, void* const* events, float* loss_poison = nullptr) {
   const Arch& a = h->arch;
   const ParamMap& pm = a.pm;
   const int D = a.D;
@@ -264,6 +270,8 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   bool fuse = h->fused_gn_bwd != 0;
   fuse = fuse && grp != nullptr;       // the fused path's bias / affine gradients ride with the grouped launches
   for (const LayerDesc& l : a.layers) fuse = fuse && dgrad_gnbwd_supported(l.gw);
+  // single-GPU steps: the dgrad chain between the first launch (output_proj) and the last (into h0) as one launch of squads
+  const bool squad_bwd = fuse && !events && !h->wgrad_mid_flush && W.sq_gact && loss_poison && h->train_squad >= 2 && train_squad_ok(h, n);
   const float keep_scale = (float)(1.0 / (1.0 - (double)h->cfg.dropout_p));
   std::vector<GnColItem> cols;
   // d gamma / d beta of the layers whose backward ran in a dgrad epilogue: memory-bound leaves, one launch per call.  They
@@ -317,7 +325,13 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   // dgrad whose epilogue is the GroupNorm+SiLU(+dropout) backward of `ln` (z / stats of that layer): writes dL/dz and dL/dy
   auto dgrad_fused = [&](const float* w, int ldw, int kin, const float* gz_next, int ldg, int nout, const LayerDesc& ln, const float* z,
                          const float* stats, float* gz_out, float* gy_buf, bool accumulate, bool with_drop, int blk,
-                         const float* w_skip = nullptr, int kin_skip = 0, float* out_skip = nullptr, bool* skip_done = nullptr) -> int {
+                         const float* w_skip = nullptr, int kin_skip = 0, float* out_skip = nullptr, bool* skip_done = nullptr,
+                         bool launch = true) -> int {
+    if (!launch) {      // the squad launch (train_squad_bwd.h) has produced gz_out / gy_buf (and the skip share): only the column sums are left to queue
+      if (skip_done && w_skip) *skip_done = true;
+      cols.push_back({gy_buf, kin, z, kin, stats, kin, ln.gw, n, grads[ln.gamma], grads[ln.beta]});
+      return OSD_OK;
+    }
     GemmArgs g{};
     g.A = w; g.lda = ldw; g.B0 = gz_next; g.ldb0 = ldg; g.K0 = nout; g.F = kin; g.P = (int)n; g.K = nout;
     g.ksplit = h->train_ksplit != 0;       // launch.h: two wave groups where a launch has ~one tile per CU and >= 32 K tiles (the first dgrad)
@@ -354,6 +368,10 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   if (fuse) {
     const LayerDesc& lz = a.layers[2 * last + 1];
     OSD_TRY(dgrad_fused(h->params[pm.out_w], Hl, Hl, d_out, D, D, lz, W.f.z2[last], W.f.st2[last], W.g_z2[last], W.g_out[last], false, false, last));
+    if (squad_bwd) {      // every dgrad between this one and the last (into h0) in one launch of squads
+      TrainSquadBwdBufs B{W.g_out.data(), W.g_z2.data(), W.g_mid.data(), W.g_z1.data(), W.g_h0, masks, drop, seed, roff};
+      OSD_TRY(train_squad_backward(h, s, W.f, B, n, W.sq_gact, W.sq_wpk_t, W.sq_bar2, W.sq_panels, loss_poison));
+    }
   } else {
     OSD_HIP(dgrad(s, h->params[pm.out_w], Hl, Hl, d_out, D, D, n, W.g_out[last], Hl, false));
   }
@@ -372,18 +390,20 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
       // dL/dz of the second half is in g_z2[b] (left by the dgrad above it); bias gradients ride with the weight gradients
       bool skip_done = false;
       OSD_TRY(wg(W.f.mid[b], C, C, W.g_z2[b], C, C, n, grads[l2.w], C, grads[l2.b]));
-      OSD_TRY(dgrad_fused(h->params[l2.w], C, C, W.g_z2[b], C, C, l1, W.f.z1[b], W.f.st1[b], W.g_z1[b], W.g_mid[b], false, drop, b));
+      OSD_TRY(dgrad_fused(h->params[l2.w], C, C, W.g_z2[b], C, C, l1, W.f.z1[b], W.f.st1[b], W.g_z1[b], W.g_mid[b], false, drop, b,
+                          nullptr, 0, nullptr, nullptr, !squad_bwd));
       OSD_TRY(wg(xin, l1.K1, l1.K1, W.g_z1[b], C, C, n, grads[l1.w], Kt, grads[l1.b]));
       if (l1.K2 > 0) OSD_TRY(wg(W.f.out[skip_block], l1.K2, l1.K2, W.g_z1[b], C, C, n, grads[l1.w] + l1.K1, Kt));
       OSD_TRY(record());
       if (b == a.n_enc && (h->wgrad_mid_flush || events)) OSD_TRY(flush_all(true));
       if (b == 0) {
-        OSD_TRY(dgrad_plain(h->params[l1.w], Kt, l1.K1, W.g_z1[b], C, C, gdst, l1.K1));
+        if (!squad_bwd) OSD_TRY(dgrad_plain(h->params[l1.w], Kt, l1.K1, W.g_z1[b], C, C, gdst, l1.K1));
       } else {
         const LayerDesc& lp = a.layers[2 * (b - 1) + 1];      // the layer that produced this block's main input
         // an encoder output already holds its skip gradient (written by the decoder block that popped it): second dependency
         OSD_TRY(dgrad_fused(h->params[l1.w], Kt, l1.K1, W.g_z1[b], C, C, lp, W.f.z2[b - 1], W.f.st2[b - 1], W.g_z2[b - 1], W.g_out[b - 1], acc,
-                            false, b - 1, l1.K2 > 0 ? h->params[l1.w] + l1.K1 : nullptr, l1.K2, l1.K2 > 0 ? W.g_out[skip_block] : nullptr, &skip_done));
+                            false, b - 1, l1.K2 > 0 ? h->params[l1.w] + l1.K1 : nullptr, l1.K2, l1.K2 > 0 ? W.g_out[skip_block] : nullptr, &skip_done,
+                            !squad_bwd));
       }
       if (l1.K2 > 0 && !skip_done) OSD_TRY(dgrad_plain(h->params[l1.w] + l1.K1, Kt, l1.K2, W.g_z1[b], C, C, W.g_out[skip_block], l1.K2));
       continue;
@@ -499,7 +519,10 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   {
     auto add = [&](float* p, int64_t c) { zl.ptr[zl.n] = p; zl.count[zl.n] = c; ++zl.n; };
     add(loss_out, 1);
-    if (w.sq_bar && train_squad_ok(h, n)) add(reinterpret_cast<float*>(w.sq_bar), w.sq_panels * 16 + 16);      // the squads' barrier counters + status word
+    if (w.sq_bar && train_squad_ok(h, n)) {      // the squads' barrier counters + status words (forward, backward)
+      add(reinterpret_cast<float*>(w.sq_bar), w.sq_panels * 16 + 16);
+      add(reinterpret_cast<float*>(w.sq_bar2), w.sq_panels * 16 + 16);
+    }
     if (cp) add(h->parts_dev, 3);
     if (cp && grads) add(w.g_x0, n * (int64_t)D);
     if (grads) add_backward_zeros(a, w, grads, &zl);
@@ -573,7 +596,7 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   }
   if (!grads) return OSD_OK;
 
-  OSD_TRY(backward_from(h, s, W, W.x_t, W.xld, t_idx, cond, n, W.d_out, train, masks, seed, roff, grads, nullptr, events));
+  OSD_TRY(backward_from(h, s, W, W.x_t, W.xld, t_idx, cond, n, W.d_out, train, masks, seed, roff, grads, nullptr, events, loss_out));
   if (flags & OSD_F_SYNC) OSD_HIP(hipStreamSynchronize(s));
   return OSD_OK;
 }

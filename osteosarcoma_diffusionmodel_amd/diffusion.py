@@ -262,7 +262,7 @@ class BiologyAwareDiffusionModel(nn.Module):
         self.train_streams: Optional[int] = None      # 1 = whole backward on one stream, 2 (library default) = weight gradients on a side stream
         # the ten Linear+GroupNorm+SiLU layers of a training forward pass as one launch of squads (csrc/train_squad.h) from 2 048 rows on:
         # None / True (library default) or False (per-layer launches)
-        self.train_squad: Optional[bool] = None
+        self.train_squad = None       # None (library default) | False / 0 | True / 1 (forward only) | 2 (forward and the dgrad chain, csrc/train_squad_bwd.h)
         # optional constraint losses (set_constraints); None = the reference's eps-MSE only
         self._constraints = None
         self._constraints_version = 0
@@ -355,7 +355,7 @@ class BiologyAwareDiffusionModel(nn.Module):
         if self.train_streams:
             L.check(L.lib().osd_set_option(eng.handle, b"train_streams", int(self.train_streams)))
         if self.train_squad is not None:
-            L.check(L.lib().osd_set_option(eng.handle, b"train_squad", int(bool(self.train_squad))))
+            L.check(L.lib().osd_set_option(eng.handle, b"train_squad", int(self.train_squad)))
         try:
             mode = {"auto": 0, "chain": 1, "graph": 2, "layers": 2}[self.sampler]
         except KeyError:

@@ -165,7 +165,7 @@ def test_config2_forward_trunk_as_one_squad_launch_vs_per_layer_launches(n):
     sd, x, cond, t, noise, _ = _inputs()
     kw = dict(t=t[:n].cuda(), noise=noise[:n].cuda(), seed=SEED)
     out = {}
-    for squad in (False, True):
+    for squad in (False, True, 2):
         m, _ = _model(2)
         m.train_squad = squad
         loss = m(x[:n].cuda(), cond[:n].cuda(), **kw)
@@ -176,6 +176,11 @@ def test_config2_forward_trunk_as_one_squad_launch_vs_per_layer_launches(n):
         assert_close(out[True][1][k], out[False][1][k], GRAD_RTOL, atol=1e-9, what=f"grad {k}, squad forward vs per-layer launches")
     # it really is another summation order (bit-equal gradients everywhere would mean the switch did nothing)
     assert any(not torch.equal(out[True][1][k], out[False][1][k]) for k in out[True][1])
+    # ... and the dgrad chain as one launch of squads as well (csrc/train_squad_bwd.h; single-GPU steps)
+    assert_close(out[2][0], out[False][0], 2e-6, what="loss, squad forward + backward vs per-layer launches")
+    for k in out[2][1]:
+        assert_close(out[2][1][k], out[False][1][k], GRAD_RTOL, atol=1e-9, what=f"grad {k}, squad forward + backward vs per-layer launches")
+    assert any(not torch.equal(out[2][1][k], out[True][1][k]) for k in out[2][1])
 
 
 def test_config2_squad_forward_that_cannot_finish_poisons_the_loss():
