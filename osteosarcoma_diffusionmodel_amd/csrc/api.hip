@@ -402,6 +402,8 @@ int osd_create(const osd_config* cfg, osd_handle** out) {
   if (const char* e = getenv("OSD_TRAIN_INPUT_SPLITK")) h->train_input_splitk = atoi(e);
   if (const char* e = getenv("OSD_DUAL_DGRAD")) h->dual_dgrad = atoi(e) != 0;
   if (const char* e = getenv("OSD_TRAIN_KSPLIT")) h->train_ksplit = atoi(e) != 0;
+  if (const char* e = getenv("OSD_COND_BWD_FUSED")) h->cond_bwd_fused = atoi(e) != 0;
+  if (const char* e = getenv("OSD_TWO_STREAM_BWD")) h->two_stream_bwd = atoi(e) != 0;
   const int rc = create_device_state(h);
   if (rc != OSD_OK) {                 // nothing of a half-built handle survives (osd_destroy frees what was allocated)
     osd_destroy(h);
@@ -509,6 +511,11 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "dual_dgrad")) {
     if (value < 0 || value > 1) { set_error("dual_dgrad must be 0 or 1"); return OSD_EINVAL; }
     h->dual_dgrad = (int)value;
+    return OSD_OK;
+  }
+  if (!strcmp(name, "cond_bwd_fused")) {
+    if (value < 0 || value > 1) { set_error("cond_bwd_fused must be 0 or 1"); return OSD_EINVAL; }
+    h->cond_bwd_fused = (int)value;
     return OSD_OK;
   }
   if (!strcmp(name, "train_input_splitk")) {

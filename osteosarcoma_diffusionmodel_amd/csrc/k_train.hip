@@ -97,6 +97,184 @@ hipError_t launch_silu_bwd(hipStream_t s, const float* u, const float* g, float*
   return hipGetLastError();
 }
 
+// ---- the conditioning branch's backward below h0, one launch instead of five (scatter_rows, two 64-wide dgrads, silu_bwd, small_wgrad) ----
+//   g_temb[t[r]][:] += g_h0[r][:]                                  (time embedding table; zeroed by the caller)
+//   g_ce2[r][k] = sum_n g_h0[r][n] W_cp[n][k]       n < H0, k < 64   (cond_proj: h0 = ... + ce2 W_cp^T)
+//   g_u[r][k]   = (sum_n g_ce2[r][n] W_ce2[n][k]) * silu'(u0[r][k]) (ConditionalEmbedding's second Linear and its SiLU)
+//   dW0[k][j] += sum_r g_u[r][k] cond[r][j],  db0[k] += sum_r g_u[r][k]      (its first Linear, cd <= 4 inputs; optional)
+// A workgroup owns 16 rows; wave w owns output columns 16 w .. + 15 of both GEMMs (v_mfma_f32_16x16x4_f32: M = 16 columns, N = the 16
+// rows, K in steps of 4).  The A operands -- the wave's column slice of W_cp (H0 / 4 registers) and of W_ce2 (16) -- are loaded straight
+// into registers, all at once, in the prologue; the B operand is the rows' g_h0 tile in LDS (row stride H0 + 4: lanes (row, k) read 64
+// different banks), which the scatter reads too.  0.17 GFLOP at batch 4 096: the five launches it replaces were launch- and latency-bound
+// (6 + 9 + 5 + 5 + 7 us alone, 50-60 us beside the column sums of the side stream), not FLOP-bound.
+// Built and dropped on the way, each parity-green:
+//   * VALU version, thread = (column, 4-8 rows), weights streamed from L2 in the K loop: 53 us -- one L2 round trip per four k;
+//   * the same with both weight matrices in LDS (101 KB, one workgroup per CU): 36-50 us, of which 28 the first GEMM's K loop: its
+//     tile reads were wave-uniform ds_read_b128 (every lane the same address), which this LDS serves at ~1/25 of the rate of a
+//     conflict-free read -- not a broadcast;
+//   * scatter atomics issued from the float4 registers of the tile copy (16 bytes between lanes: four times the cache lines per
+//     instruction), a t[row] load inside the scatter loop (a vmcnt(0) wait, which the atomics count on too, in front of every atomic),
+//     loads whose only use was a store under a branch (hipcc sinks the load into the branch and drains vmcnt there: 24 serial L2 round
+//     trips in the prologue), __threadfence() before the ticket (an agent-scope release writes back the XCD's whole L2: 97 us, and the
+//     column sums beside it 100 instead of 43).
+typedef float cb_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_cond_bwd(const float* __restrict__ g_h0, int H0, const int* __restrict__ t, float* g_temb,
+                                                  const float* __restrict__ w_cp, const float* __restrict__ w_ce2,
+                                                  const float* __restrict__ u0, int64_t rows, float* __restrict__ g_ce2, float* __restrict__ g_u,
+                                                  const float* __restrict__ cond, int cd, float* part, float* dw0, float* db0) {
+  constexpr int R = 16;
+  extern __shared__ float cb_lds[];
+  const int ldt = H0 + 4;
+  float* tile = cb_lds;                 // [16][H0 + 4]; later the [64 (cd + 1)] exchange of the small weight gradient
+  float* g2 = tile + R * ldt;           // [16][68]
+  __shared__ int cb_t[R];
+  __shared__ float cb_c[R * 4];         // the rows' conditions, [16][4] with zeros behind cd and behind the last row
+  __shared__ int cb_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, kg = lane >> 4, col0 = wave * 16;
+  const int64_t row0 = (int64_t)blockIdx.x * R, last_row = rows - 1;
+  const int q = H0 >> 2;
+  // ---- prologue: every global load of the kernel, none under a branch, nothing stored before all are issued ----
+  float a1[64], a2[16];                 // A[m][k]: lane (m, kg) holds W[4 ks + kg][col0 + m]
+#pragma unroll
+  for (int ks = 0; ks < 64; ++ks) { const int kr = 4 * ks + kg; a1[ks] = w_cp[(kr < H0 ? kr : H0 - 1) * 64 + col0 + m]; }
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) a2[ks] = w_ce2[(4 * ks + kg) * 64 + col0 + m];
+  // this lane's outputs (the accumulator fragment): row m of the tile, columns col0 + 4 kg .. + 3
+  const int64_t orow = row0 + m;
+  const float4 ux = *reinterpret_cast<const float4*>(u0 + (orow < rows ? orow : last_row) * 64 + col0 + 4 * kg);
+  {
+    const int64_t row = row0 + (tid & (R - 1));                      // threads 16.. write the same values again
+    const int tv = t[row < rows ? row : last_row];
+    const int ci = tid & (4 * R - 1), cr = ci >> 2, cj = ci & 3;
+    const int64_t crow = row0 + cr;
+    const float cv = (cond ? cond : u0)[(crow < rows ? crow : last_row) * (cond ? cd : 0) + (cj < cd ? cj : 0)];
+    float4 v[4];
+    for (int base = tid; base < R * q; base += 256 * 4) {      // 1 024 float4 at H0 = 256: one round of four loads
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + 256 * u, ic = i < R * q ? i : R * q - 1;
+        const int r = ic / q, c4 = ic - r * q;
+        const int64_t grow = row0 + r;
+        v[u] = *reinterpret_cast<const float4*>(g_h0 + (grow < rows ? grow : last_row) * H0 + 4 * c4);
+        if (grow >= rows) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {      // behind the end: the last element once more, to its own place
+        const int i = base + 256 * u, ic = i < R * q ? i : R * q - 1;
+        const int r = ic / q, c4 = ic - r * q;
+        *reinterpret_cast<float4*>(tile + r * ldt + 4 * c4) = v[u];
+      }
+    }
+    cb_t[tid & (R - 1)] = (g_temb && row < rows) ? tv : -1;
+    cb_c[ci] = (cond && cj < cd && crow < rows) ? cv : 0.f;
+  }
+  __syncthreads();
+  // ---- g_ce2 = g_h0 W_cp: B[k][n] = tile[n][k], lane (n = m, kg) reads tile[m][4 ks + kg] ----
+  cb_f4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* brow = tile + m * ldt + kg;
+#pragma unroll
+  for (int g = 0; g < 8; ++g)
+    if (8 * g < q) {                     // H0 is a multiple of 32: whole groups of eight K steps
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[8 * g + e], brow[4 * (8 * g + e)], acc, 0, 0, 0);
+    }
+  // the scatter (behind the first GEMM's LDS reads, so that its atomics drain under the rest of the kernel): lanes = consecutive
+  // columns of one row, one atomic instruction covers 256 contiguous bytes; the rows' t come from LDS
+  if (g_temb)
+    for (int i = tid; i < R * H0; i += 256) {
+      const int r = i / H0, c = i - r * H0;
+      const int tr = cb_t[r];
+      if (tr >= 0) atomicAdd(g_temb + (int64_t)tr * H0 + c, tile[r * ldt + c]);
+    }
+  // D[mm][n]: lane (n = m, kg) holds columns col0 + 4 kg .. + 3 of row m
+  if (orow < rows) *reinterpret_cast<float4*>(g_ce2 + orow * 64 + col0 + 4 * kg) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  *reinterpret_cast<float4*>(g2 + m * 68 + col0 + 4 * kg) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  // ---- g_ce1 = g_ce2 W_ce2, then the SiLU backward ----
+  cb_f4 acc2 = {0.f, 0.f, 0.f, 0.f};
+  const float* b2 = g2 + m * 68 + kg;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[ks], b2[4 * ks], acc2, 0, 0, 0);
+  float gu[4];
+  {
+    const float xs[4] = {ux.x, ux.y, ux.z, ux.w};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float sg = sigmoid_f(xs[v]);
+      gu[v] = acc2[v] * (sg * (1.0f + xs[v] * (1.0f - sg)));      // rows behind the last: acc2 = 0 (their tile rows are zero)
+    }
+  }
+  if (orow < rows) *reinterpret_cast<float4*>(g_u + orow * 64 + col0 + 4 * kg) = make_float4(gu[0], gu[1], gu[2], gu[3]);
+  if (!cond) return;
+  // ---- ConditionalEmbedding's first Linear: sums over the 16 rows = over the 16 lanes that share kg ----
+  // Every workgroup adding into the same 64 (cd + 1) addresses serialises in one L2 channel (k_small_wgrad below: 7 us alone with 16
+  // blocks, 18 beside the column sums), so the workgroups add into 16 copies 4 KB apart and the last one to finish folds the copies
+  // into the gradient (and leaves copies and counter zero again).
+  const float4 cr4 = *reinterpret_cast<const float4*>(cb_c + m * 4);
+  const float cs[4] = {cr4.x, cr4.y, cr4.z, cr4.w};
+  float ps[5][4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    ps[0][v] = gu[v];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ps[1 + j][v] = gu[v] * cs[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float x = ps[j][v];
+      x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
+      ps[j][v] = x;
+    }
+  float* red = tile;                    // the scatter above has read the tile: wait for every wave before overwriting it
+  __syncthreads();
+  if (m == 0) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int n = col0 + 4 * kg + v;
+      red[64 * cd + n] = ps[0][v];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (j < cd) red[n * cd + j] = ps[1 + j][v];
+    }
+  }
+  __syncthreads();
+  const int nv = 64 * (cd + 1);
+  float* mine = part + (blockIdx.x & 15) * 1024;
+  for (int i = tid; i < nv; i += 256) atomicAdd(mine + i, red[i]);
+  // every atomic of this workgroup acknowledged by L2 before its ticket is drawn: a counter wait, not __threadfence() (see above)
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __syncthreads();
+  unsigned* counter = reinterpret_cast<unsigned*>(part + 16 * 1024);
+  if (tid == 0) cb_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!cb_last) return;
+  for (int i = tid; i < nv; i += 256) {
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) sum += __hip_atomic_load(part + c * 1024 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) part[c * 1024 + i] = 0.f;
+    if (i < 64 * cd) dw0[i] += sum; else db0[i - 64 * cd] += sum;
+  }
+  if (tid == 0) *counter = 0u;
+}
+// shapes and alignments the one-launch kernel takes (H0 / 4 <= 64 weight registers per lane, whole groups of eight K steps, float4 accesses)
+bool cond_bwd_ok(int H0, const float* g_h0, const float* u0, const float* g_ce2, const float* g_u) {
+  if (H0 < 32 || H0 % 32 != 0 || H0 > 256) return false;
+  return (((uintptr_t)g_h0 | (uintptr_t)u0 | (uintptr_t)g_ce2 | (uintptr_t)g_u) & 15) == 0;
+}
+hipError_t launch_cond_bwd(hipStream_t s, const float* g_h0, int H0, const int* t, float* g_temb, const float* w_cp, const float* w_ce2,
+                           const float* u0, int64_t rows, float* g_ce2, float* g_u, const float* cond, int cd, float* part, float* dw0, float* db0) {
+  if (rows <= 0) return hipSuccess;
+  if (!cond_bwd_ok(H0, g_h0, u0, g_ce2, g_u)) return hipErrorInvalidValue;
+  if (cond && (cd < 1 || cd > 4 || !part || !dw0 || !db0)) return hipErrorInvalidValue;
+  const size_t lds = (size_t)(16 * (H0 + 4) + 16 * 68) * sizeof(float);      // <= 21 KB
+  hipLaunchKernelGGL(k_cond_bwd, (unsigned)((rows + 15) / 16), 256, lds, s, g_h0, H0, t, g_temb, w_cp, w_ce2, u0, rows, g_ce2, g_u, cond, cd, part, dw0, db0);
+  return hipGetLastError();
+}
+
 // ---- column sums: out[c] += sum_r in[r][c]   (out zeroed by the caller) --------------------
 __global__ void k_colsum(const float* in, int ld, int64_t rows, int cols, int rows_per_block, float* out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -354,7 +532,8 @@ __global__ __launch_bounds__(1024) void k_small_wgrad(const float* x, int kin, c
 hipError_t launch_small_wgrad(hipStream_t s, const float* x, int kin, const float* gz, int ldg, int nout, int64_t rows, float* dw, float* dbias) {
   if (rows <= 0) return hipSuccess;
   if (nout * kin > 256) return hipErrorInvalidValue;
-  const int rpb = 64;
+  // one atomic per output and block: the atomics on <= 256 addresses of one L2 channel serialise, so big batches take fewer, longer blocks
+  const int rpb = rows >= 4096 ? 256 : 64;
   hipLaunchKernelGGL(k_small_wgrad, (unsigned)((rows + rpb - 1) / rpb), 1024, 0, s, x, kin, gz, ldg, nout, rows, rpb, dw, dbias);
   return hipGetLastError();
 }

@@ -14,6 +14,14 @@ hipError_t launch_cond_mlp_fwd(hipStream_t s, const float* cond, int cd, const f
 hipError_t launch_silu_bwd(hipStream_t s, const float* u, const float* g, float* gu, int64_t total);
 hipError_t launch_colsum(hipStream_t s, const float* in, int ld, int64_t rows, int cols, float* out);
 hipError_t launch_scatter_rows(hipStream_t s, const float* g, const int* t, int64_t rows, int cols, float* table);
+// scatter_rows + the dgrads of cond_proj and ConditionalEmbedding's second Linear + its SiLU backward (+ its first Linear's weight gradient) in one launch (k_train.hip)
+bool cond_bwd_ok(int H0, const float* g_h0, const float* u0, const float* g_ce2, const float* g_u);
+hipError_t launch_cond_bwd(hipStream_t s, const float* g_h0, int H0, const int* t, float* g_temb, const float* w_cp, const float* w_ce2,
+                           const float* u0, int64_t rows, float* g_ce2, float* g_u,
+                           // optional (cond != null, cd <= 4): ConditionalEmbedding's first Linear's weight and bias gradients ADDED into dw0 [64][cd] / db0 [64];
+                           // part: COND_BWD_PART_FLOATS zeroed floats (16 partial copies + a counter; the kernel leaves them zero)
+                           const float* cond, int cd, float* part, float* dw0, float* db0);
+constexpr int COND_BWD_PART_FLOATS = 16 * 1024 + 64;
 
 struct GnBwdArgs {
   const float* g;        // dL/d(output of the half block) [rows][C]

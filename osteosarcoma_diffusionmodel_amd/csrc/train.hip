@@ -54,7 +54,7 @@ static int64_t carve_train(const Arch& a, float* base, int64_t n, const ConsPlan
   w->cond_mix = take(n * (int64_t)a.cond_dim);
   w->t_idx = (int*)take(n);
   w->g_h0 = take(n * a.H0); w->g_ce2 = take(n * 64); w->g_ce1 = take(n * 64); w->g_u = take(n * 64);
-  w->g_temb = take((int64_t)t_pad(a.T) * a.H0);
+  w->g_temb = take((int64_t)t_pad(a.T) * a.H0 + COND_BWD_PART_FLOATS);      // + k_cond_bwd's partial copies (zeroed with the table)
   w->g_out.resize(a.n_blocks); w->g_z2.resize(a.n_blocks); w->g_mid.resize(a.n_blocks); w->g_z1.resize(a.n_blocks);
   for (int b = 0; b < a.n_blocks; ++b) {
     const int64_t c = a.block_out[b];
@@ -155,7 +155,7 @@ static int cond_embed_fwd(osd_handle* h, hipStream_t s, const float* cond, int64
 static void add_backward_zeros(const Arch& a, const TrainWs& w, float* const* grads, ZeroList* zl) {
   const ParamMap& pm = a.pm;
   auto add = [&](float* p, int64_t c) { zl->ptr[zl->n] = p; zl->count[zl->n] = c; ++zl->n; };
-  add(w.g_temb, (int64_t)t_pad(a.T) * a.H0);
+  add(w.g_temb, (int64_t)t_pad(a.T) * a.H0 + COND_BWD_PART_FLOATS);
   const int small[] = {pm.ce0_b, pm.ce2_b, pm.in_b, pm.cp_b, pm.tp_b, pm.out_b};
   for (int i : small) add(grads[i], pm.numel[i]);
   if (small_wgrad_ok(a.cond_dim, 64, a.cond_dim)) add(grads[pm.ce0_w], pm.numel[pm.ce0_w]);     // k_small_wgrad adds into it
@@ -448,14 +448,25 @@ static int backward_from(osd_handle* h, hipStream_t s, TrainWs& W, const float* 
   if (dx_t) OSD_HIP(dgrad(s, h->params[pm.in_w], D, D, W.g_h0, a.H0, a.H0, n, dx_t, D, false));
   OSD_TRY(wg(x_t, x_ld, D, W.g_h0, a.H0, a.H0, n, grads[pm.in_w], D, grads[pm.in_b], grads[pm.cp_b], grads[pm.tp_b]));
   OSD_TRY(wg(W.f.ce2, 64, 64, W.g_h0, a.H0, a.H0, n, grads[pm.cp_w], 64));
-  OSD_HIP(launch_scatter_rows(s, W.g_h0, t_idx, n, a.H0, W.g_temb));
-  OSD_HIP(dgrad(s, h->params[pm.cp_w], 64, 64, W.g_h0, a.H0, a.H0, n, W.g_ce2, 64, false));
+  // the branch below h0 (scatter into the time table, cond_proj's and the second embedding Linear's dgrads, SiLU backward): one launch
+  const bool cond_fused = h->cond_bwd_fused && cond_bwd_ok(a.H0, W.g_h0, W.u0, W.g_ce2, W.g_u);
+  // ... and, where the first embedding Linear has at most four inputs (k_small_wgrad's case), its weight gradient rides along
+  const bool ce0_fused = cond_fused && a.cond_dim <= 4 && small_wgrad_ok(a.cond_dim, 64, a.cond_dim);
+  if (cond_fused) {
+    OSD_HIP(launch_cond_bwd(s, W.g_h0, a.H0, t_idx, W.g_temb, h->params[pm.cp_w], h->params[pm.ce2_w], W.u0, n, W.g_ce2, W.g_u,
+                            ce0_fused ? cond : nullptr, a.cond_dim, W.g_temb + (int64_t)t_pad(a.T) * a.H0, grads[pm.ce0_w], grads[pm.ce0_b]));
+  } else {
+    OSD_HIP(launch_scatter_rows(s, W.g_h0, t_idx, n, a.H0, W.g_temb));
+    OSD_HIP(dgrad(s, h->params[pm.cp_w], 64, 64, W.g_h0, a.H0, a.H0, n, W.g_ce2, 64, false));
+  }
   // both tables carry zero rows up to a multiple of 32 (whole K steps of the grouped kernel): they add nothing
   OSD_TRY(wg(h->d_time_emb, a.time_dim, a.time_dim, W.g_temb, a.H0, a.H0, t_pad(a.T), grads[pm.tp_w], a.time_dim));
   OSD_TRY(wg(W.f.ce1, 64, 64, W.g_ce2, 64, 64, n, grads[pm.ce2_w], 64, grads[pm.ce2_b]));
-  OSD_HIP(dgrad(s, h->params[pm.ce2_w], 64, 64, W.g_ce2, 64, 64, n, W.g_ce1, 64, false));
-  OSD_HIP(launch_silu_bwd(s, W.u0, W.g_ce1, W.g_u, n * 64));
-  OSD_TRY(wg(cond, a.cond_dim, a.cond_dim, W.g_u, 64, 64, n, grads[pm.ce0_w], a.cond_dim, grads[pm.ce0_b]));
+  if (!cond_fused) {
+    OSD_HIP(dgrad(s, h->params[pm.ce2_w], 64, 64, W.g_ce2, 64, 64, n, W.g_ce1, 64, false));
+    OSD_HIP(launch_silu_bwd(s, W.u0, W.g_ce1, W.g_u, n * 64));
+  }
+  if (!ce0_fused) OSD_TRY(wg(cond, a.cond_dim, a.cond_dim, W.g_u, 64, 64, n, grads[pm.ce0_w], a.cond_dim, grads[pm.ce0_b]));
   OSD_TRY(record());
   OSD_TRY(flush_all(false));          // ends with the side stream joined: the caller's stream owns every result again
   return OSD_OK;

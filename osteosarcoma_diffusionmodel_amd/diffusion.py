@@ -263,6 +263,9 @@ class BiologyAwareDiffusionModel(nn.Module):
         # the ten Linear+GroupNorm+SiLU layers of a training forward pass as one launch of squads (csrc/train_squad.h) from 2 048 rows on:
         # None / True (library default) or False (per-layer launches)
         self.train_squad = None       # None (library default) | False / 0 | True / 1 (forward only) | 2 (forward and the dgrad chain, csrc/train_squad_bwd.h)
+        # the conditioning branch's backward below h0 (time-table scatter, two 64-wide dgrads, SiLU backward) as one launch
+        # (k_cond_bwd, csrc/k_train.hip): None / True (library default) or False (four launches)
+        self.cond_bwd_fused = None
         # optional constraint losses (set_constraints); None = the reference's eps-MSE only
         self._constraints = None
         self._constraints_version = 0
@@ -356,6 +359,8 @@ class BiologyAwareDiffusionModel(nn.Module):
             L.check(L.lib().osd_set_option(eng.handle, b"train_streams", int(self.train_streams)))
         if self.train_squad is not None:
             L.check(L.lib().osd_set_option(eng.handle, b"train_squad", int(self.train_squad)))
+        if self.cond_bwd_fused is not None:
+            L.check(L.lib().osd_set_option(eng.handle, b"cond_bwd_fused", int(bool(self.cond_bwd_fused))))
         try:
             mode = {"auto": 0, "chain": 1, "graph": 2, "layers": 2}[self.sampler]
         except KeyError:

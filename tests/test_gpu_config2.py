@@ -183,6 +183,30 @@ def test_config2_forward_trunk_as_one_squad_launch_vs_per_layer_launches(n):
     assert any(not torch.equal(out[2][1][k], out[True][1][k]) for k in out[2][1])
 
 
+@pytest.mark.parametrize("n", [4096, 2100, 37])
+def test_config2_conditioning_branch_backward_as_one_launch_vs_four(n):
+    """k_cond_bwd (csrc/k_train.hip): below h0 the backward of the conditioning branch -- the scatter of dL/dh0 into the time table's
+    rows, cond_proj's and ConditionalEmbedding's second Linear's dgrads, the SiLU backward -- is one launch of 32-row workgroups
+    instead of four dependent ones.  Same inputs, same draws: every gradient against the four-launch path (``cond_bwd_fused =
+    False``); the six tensors it feeds (time_proj, cond_proj and the embedding's weights) must not be bit-equal everywhere -- the
+    sums run in another order -- and a ragged last workgroup (2 100 = 65 * 32 + 20 rows; 37 rows) is covered."""
+    sd, x, cond, t, noise, _ = _inputs()
+    kw = dict(t=t[:n].cuda(), noise=noise[:n].cuda(), seed=SEED)
+    out = {}
+    for fused in (False, True):
+        m, _ = _model(2)
+        m.cond_bwd_fused = fused
+        loss = m(x[:n].cuda(), cond[:n].cuda(), **kw)
+        loss.backward()
+        out[fused] = (loss.item(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()})
+    assert_close(out[True][0], out[False][0], 2e-6, what="loss (the forward pass is the same)")
+    for k in out[True][1]:
+        assert_close(out[True][1][k], out[False][1][k], GRAD_RTOL, atol=1e-9, what=f"grad {k}, one-launch conditioning backward vs four launches")
+    branch = [k for k in out[True][1] if k.startswith("condition_embed") or "time_proj" in k or "cond_proj" in k]
+    assert len(branch) >= 6, branch
+    assert any(not torch.equal(out[True][1][k], out[False][1][k]) for k in branch)
+
+
 def test_config2_squad_forward_that_cannot_finish_poisons_the_loss():
     """A training step has no second engine to fall back to inside the call.  A squad whose barrier runs into the spin budget (here:
     one tick) leaves, raises the status word and writes NaN into the loss accumulator: the step's loss is NaN -- visible to

@@ -29,4 +29,5 @@ for r in rows[a:b]:
     q = r.get("Stream_Id", r.get("Queue_Id", "?"))
     gap = s - prev_end.get(q, s)
     prev_end[q] = e
-    print(f"{s/1e3:9.1f} {e/1e3:9.1f} {(e-s)/1e3:7.1f} gap {gap/1e3:6.1f} q{q} {short(r['Kernel_Name'])}")
+    wgs = int(r.get("Grid_Size_X", 0) or 0) // max(1, int(r.get("Workgroup_Size_X", 1) or 1)) * max(1, int(r.get("Grid_Size_Y", 1) or 1))
+    print(f"{s/1e3:9.1f} {e/1e3:9.1f} {(e-s)/1e3:7.1f} gap {gap/1e3:6.1f} q{q} wg{wgs:<5d} {short(r['Kernel_Name'])}")
