@@ -99,8 +99,12 @@ int osd_set_stream(osd_handle *h, void *hip_stream);
  * resident -- 3 072 rows on 256 CUs --, others run what auto would; it agrees with the other engines to fp32 rounding, not bitwise
  * ("squad_panel": its patients per panel, 0 auto = 16 up to 1 024 rows and 32 above, or 16 / 32; "last_squad_panel" reads back);
  * 0 auto: 1 from 65 536 rows on, 2 from 10 240 rows on, 3 for resident batches when "input_splitk" != 0), "dual_dgrad" / "train_ksplit" /
- * "train_input_splitk" (training-step experiments), "train_squad" (1, the default: from 2 048 rows on the ten
- * Linear+GroupNorm+SiLU layers of a training forward pass run as one launch of squads, csrc/train_squad.h; 0: per-layer launches),
+ * "train_input_splitk" (training-step experiments), "train_squad" (from 2 048 rows on: 2, the default, runs the ten
+ * Linear+GroupNorm+SiLU layers of a training forward pass as one launch of squads, csrc/train_squad.h, and the dgrad chain of the backward
+ * pass as another, csrc/train_squad_bwd.h -- the backward one in single-process steps only: bucket events or a mid-pass flush keep the
+ * per-layer dgrads --; 1: the forward only; 0: per-layer launches), "cond_bwd_fused" (1, the default: the conditioning branch's backward
+ * below h0 -- time-table scatter, two 64-wide dgrads, SiLU backward, the first embedding Linear's weight gradient -- as one launch,
+ * k_cond_bwd in csrc/k_train.hip, for hidden_dims[0] <= 256 and a multiple of 32; 0: five launches),
  * "input_splitk" (the small-batch mode of sampling: 0 off --
  * the default: a row's result does not depend on the batch it is in, bit for bit --, -1 auto, n > 0 slices: small batches run
  * input_proj and the deep layers split over K, or, where chain_variant 3 applies, the squad chain; another fp32 summation order,

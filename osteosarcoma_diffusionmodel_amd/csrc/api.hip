@@ -472,7 +472,7 @@ int osd_set_option(osd_handle* h, const char* name, int64_t value) {
     h->sampler = (int)value;
     return OSD_OK;
   }
-  if (!strcmp(name, "train_squad")) {             // 1 (default): the trunk of a training forward pass as one launch of squads from 2 048 rows on (train_squad.h); 0: per-layer launches
+  if (!strcmp(name, "train_squad")) {             // from 2 048 rows on: 2 (default) the trunk of a training forward pass AND the dgrad chain each as one launch of squads (train_squad.h, train_squad_bwd.h; the backward one in single-process steps), 1 the forward only, 0 per-layer launches
     if (value < 0 || value > 2) { set_error("train_squad must be 0 (per-layer launches), 1 (forward trunk as squads) or 2 (forward and the dgrad chain)"); return OSD_EINVAL; }
     h->train_squad = (int)value;
     return OSD_OK;
@@ -579,7 +579,7 @@ int osd_get_option(osd_handle* h, const char* name, int64_t* value) {
       {"precision", h->precision}, {"last_precision", h->last_precision}, {"split_supported", split_supported(h->arch) ? 1 : 0},
       {"chain_fallbacks", h->chain_fallbacks}, {"last_engine", h->last_engine},
       {"chain_variant", h->chain_variant}, {"last_chain_variant", h->last_chain_variant}, {"panel_chain_supported", panel_chain_supported(h) ? 1 : 0},
-      {"squad_chain_supported", squad_chain_supported(h) ? 1 : 0}, {"last_squad_panel", h->last_squad_rp}, {"squad_panel", h->squad_panel}, {"train_squad", h->train_squad}};
+      {"squad_chain_supported", squad_chain_supported(h) ? 1 : 0}, {"last_squad_panel", h->last_squad_rp}, {"squad_panel", h->squad_panel}, {"train_squad", h->train_squad}, {"cond_bwd_fused", h->cond_bwd_fused}};
   for (const auto& e : tab)
     if (!strcmp(name, e.n)) { *value = e.v; return OSD_OK; }
   set_error("unknown option '%s'", name);
