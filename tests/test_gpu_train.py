@@ -291,13 +291,15 @@ def test_custom_loss_through_differentiable_predict_noise(golden_dir, mode):
         e1.sum().backward()
 
 
-@pytest.mark.parametrize("cond_dim", [8, 12, 6])
+@pytest.mark.parametrize("cond_dim", [8, 12, 6, 4, 1])
 @pytest.mark.parametrize("train_streams", [1, 2])
 def test_wide_condition_grads_vs_oracle(cond_dim, train_streams):
     """condition_dim 8 / 12: the ConditionalEmbedding's first weight gradient (64 x cond_dim) is neither the small kernel's
     (cond_dim <= 4) nor the grouped launch's (k_in >= 16) and takes the immediate split-K path on the side stream, which shares
     the slab workspace with the end-of-pass grouped launch on the main stream (round-2 advisor finding: the main stream must
-    wait for it).  cond_dim 6 takes the guarded path without slabs.  Multi-slice batch so that the slabs are really used."""
+    wait for it).  cond_dim 6 takes the guarded path without slabs.  Multi-slice batch so that the slabs are really used.
+    cond_dim 4 / 1: the widest and the narrowest first Linear whose weight gradient rides inside k_cond_bwd (csrc/k_train.hip:
+    16 partial copies folded by the last workgroup), here at hidden_dims[0] = 64 -- two of the eight K groups of its first GEMM."""
     dims = dict(mutation_dim=8, expression_dim=48, pathway_dim=8, condition_dim=cond_dim)
     H = [64, 128, 64]
     shapes = O.param_shapes(8, 48, 8, cond_dim, H, 128)
