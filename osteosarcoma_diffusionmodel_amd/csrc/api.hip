@@ -262,6 +262,7 @@ int refresh_derived(osd_handle* h, hipStream_t s, bool pack_in_w) {
   OSD_HIP(launch_linear(s, g, true, true, h->params[a.pm.tp_b], h->d_temb, a.H0, false, false));
   h->panel_wpk_valid = false;           // the LDS-resident chain repacks its fragment-ordered copies before its next run
   h->squad_wpk_valid[0] = h->squad_wpk_valid[1] = false;      // ... and the squad chains theirs
+  h->sq_wpk_t_fresh = false;
   h->split_valid = false;               // ... and the bf16x3 engine its weight planes
   if (!pack_in_w) {                     // a training step that reads input_proj.weight directly: the packed copies go stale and are
     h->w_packed_stale = true;           // refreshed by the next entry point that reads them (ensure_packed) or osd_load_weights

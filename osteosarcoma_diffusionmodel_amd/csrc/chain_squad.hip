@@ -300,8 +300,7 @@ int squad_chain_run(osd_handle* h, const float* cond, int64_t n, const float* x_
 // ---- the training forward trunk as one launch of squads (train_squad.h) ----------------------------------------------------------
 // every layer's weight into fragment order in ONE launch (blockIdx.y = layer): the parameters change every step
 struct PackMulti { const float* w[SQ_MAX_LAYERS]; int F[SQ_MAX_LAYERS], K[SQ_MAX_LAYERS]; long long off[SQ_MAX_LAYERS]; };
-__global__ void k_pack_fragments_multi(PackMulti pm, float* __restrict__ dst) {
-  const int l = blockIdx.y;
+__device__ __forceinline__ void pack_multi_item(const PackMulti& pm, float* __restrict__ dst, int l) {
   const float* __restrict__ w = pm.w[l];
   const int F = pm.F[l], K = pm.K[l], K8 = K / 8;
   const long long total = (long long)(F / 32) * K8 * 64;
@@ -312,6 +311,50 @@ __global__ void k_pack_fragments_multi(PackMulti pm, float* __restrict__ dst) {
     const int i8 = (int)(blk % K8), fb = (int)(blk / K8);
     out[i] = *reinterpret_cast<const float4*>(w + (size_t)(32 * fb + (lane & 31)) * K + 8 * i8 + 4 * (lane >> 5));
   }
+}
+__global__ void k_pack_fragments_multi(PackMulti pm, float* __restrict__ dst) { pack_multi_item(pm, dst, blockIdx.y); }
+
+// the backward squads' copies (train_squad_bwd.h): fragment order of W^T for a block of columns,
+// dst[((fb * K8 + i) * 64 + lane) * 4 + e] = W[8 i + 4 (lane >> 5) + e][c0 + 32 fb + (lane & 31)]
+struct PackMultiT { const float* w[2 * SQ_MAX_LAYERS]; int ldw[2 * SQ_MAX_LAYERS], c0[2 * SQ_MAX_LAYERS], F[2 * SQ_MAX_LAYERS], K[2 * SQ_MAX_LAYERS]; long long off[2 * SQ_MAX_LAYERS]; };
+__device__ __forceinline__ void pack_multi_t_item(const PackMultiT& pm, float* __restrict__ dst, int l) {
+  const float* __restrict__ w = pm.w[l];
+  const int ldw = pm.ldw[l], c0 = pm.c0[l], F = pm.F[l], K8 = pm.K[l] / 8;
+  const long long total = (long long)(F / 32) * K8 * 64;
+  float4* const out = reinterpret_cast<float4*>(dst + pm.off[l]);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long long blk = i >> 6;
+    const int i8 = (int)(blk % K8), fb = (int)(blk / K8);
+    const float* r = w + (size_t)(8 * i8 + 4 * (lane >> 5)) * ldw + c0 + 32 * fb + (lane & 31);
+    out[i] = make_float4(r[0], r[ldw], r[2 * (size_t)ldw], r[3 * (size_t)ldw]);
+  }
+}
+__global__ void k_pack_fragments_multi_t(PackMultiT pm, float* __restrict__ dst) { pack_multi_t_item(pm, dst, blockIdx.y); }
+// both sets in one launch (a training step that will run the backward squads too): blockIdx.y < nl = a forward layer, else a backward item
+__global__ void k_pack_fragments_both(PackMulti pm, float* __restrict__ dst, int nl, PackMultiT pt, float* __restrict__ dst_t) {
+  if ((int)blockIdx.y < nl) pack_multi_item(pm, dst, blockIdx.y);
+  else pack_multi_t_item(pt, dst_t, (int)blockIdx.y - nl);
+}
+// The backward items in the order train_squad_backward walks its phases (their offsets are the phases' w_off / skip_w_off).
+static int bwd_pack_list(const osd_handle* h, PackMultiT* pm, long long* floats) {
+  const Arch& a = h->arch;
+  int npk = 0;
+  long long woff = 0;
+  auto pack = [&](const float* w, int ldw, int c0, int F, int K) {
+    pm->w[npk] = w; pm->ldw[npk] = ldw; pm->c0[npk] = c0; pm->F[npk] = F; pm->K[npk] = K; pm->off[npk] = woff; ++npk;
+    woff += (long long)F * K;
+  };
+  for (int b = a.n_blocks - 1; b >= 0; --b) {
+    const LayerDesc& l1 = a.layers[2 * b];
+    const LayerDesc& l2 = a.layers[2 * b + 1];
+    const int C = l1.N, Kt = l1.K1 + l1.K2;
+    pack(h->params[l2.w], C, 0, C, C);
+    pack(h->params[l1.w], Kt, 0, l1.K1, C);
+    if (b > 0 && l1.K2 > 0) pack(h->params[l1.w], Kt, l1.K1, l1.K2, C);
+  }
+  if (floats) *floats = woff;
+  return npk;
 }
 
 // floats of unit-order activations per 32-patient sub-panel (0 = the model is outside the squad decomposition) and of the
@@ -331,7 +374,7 @@ bool train_squad_ok(const osd_handle* h, int64_t n) {
 }
 
 int train_squad_forward(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in, float* act_units, float* wpk, unsigned* bar_and_status,
-                        int64_t panels, float* loss_poison) {
+                        int64_t panels, float* loss_poison, float* wpk_t) {
   const Arch& a = h->arch;
   const SquadPlan p = make_plan(a, SQ_RP);
   if (!p.ok) { set_error("internal: the squad forward is not available for this model"); return OSD_EUNSUPPORTED; }
@@ -361,8 +404,18 @@ int train_squad_forward(osd_handle* h, hipStream_t s, const FwdWs& ws, const Tru
     }
   ta.n_layers = p.n_layers;
   ta.wpk = wpk; ta.wpk_floats = p.in_off;            // the trunk weights come first in the plan's order
-  hipLaunchKernelGGL(k_pack_fragments_multi, dim3(128, (unsigned)p.n_layers), dim3(256), 0, s, pm, wpk);
-  OSD_HIP(hipGetLastError());
+  // wpk_t: this step's backward will run as squads too (train_squad_backward) -- its transposed copies ride in the same launch
+  h->sq_wpk_t_fresh = false;
+  if (wpk_t) {
+    PackMultiT pt{};
+    const int npk = bwd_pack_list(h, &pt, nullptr);
+    hipLaunchKernelGGL(k_pack_fragments_both, dim3(128, (unsigned)(p.n_layers + npk)), dim3(256), 0, s, pm, wpk, p.n_layers, pt, wpk_t);
+    OSD_HIP(hipGetLastError());
+    h->sq_wpk_t_fresh = true;
+  } else {
+    hipLaunchKernelGGL(k_pack_fragments_multi, dim3(128, (unsigned)p.n_layers), dim3(256), 0, s, pm, wpk);
+    OSD_HIP(hipGetLastError());
+  }
   ta.h0 = ws.h0; ta.ldh = a.H0; ta.h0_out = p.h0_out;
   ta.n = (int)in.n;
   ta.act = act_units; ta.act_stride = p.act_floats;
@@ -378,23 +431,6 @@ int train_squad_forward(osd_handle* h, hipStream_t s, const FwdWs& ws, const Tru
 }
 
 // ---- the backward pass's dgrad chain as one launch of squads (train_squad_bwd.h) --------------------------------------------------
-// fragment order of W^T for a block of columns: dst[((fb * K8 + i) * 64 + lane) * 4 + e] = W[8 i + 4 (lane >> 5) + e][c0 + 32 fb + (lane & 31)]
-struct PackMultiT { const float* w[2 * SQ_MAX_LAYERS]; int ldw[2 * SQ_MAX_LAYERS], c0[2 * SQ_MAX_LAYERS], F[2 * SQ_MAX_LAYERS], K[2 * SQ_MAX_LAYERS]; long long off[2 * SQ_MAX_LAYERS]; };
-__global__ void k_pack_fragments_multi_t(PackMultiT pm, float* __restrict__ dst) {
-  const int l = blockIdx.y;
-  const float* __restrict__ w = pm.w[l];
-  const int ldw = pm.ldw[l], c0 = pm.c0[l], F = pm.F[l], K8 = pm.K[l] / 8;
-  const long long total = (long long)(F / 32) * K8 * 64;
-  float4* const out = reinterpret_cast<float4*>(dst + pm.off[l]);
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int lane = (int)(i & 63);
-    const long long blk = i >> 6;
-    const int i8 = (int)(blk % K8), fb = (int)(blk / K8);
-    const float* r = w + (size_t)(8 * i8 + 4 * (lane >> 5)) * ldw + c0 + 32 * fb + (lane & 31);
-    out[i] = make_float4(r[0], r[ldw], r[2 * (size_t)ldw], r[3 * (size_t)ldw]);
-  }
-}
-
 int64_t train_squad_bwd_wpk_floats(const Arch& a) {
   int64_t f = 0;
   for (const LayerDesc& ld : a.layers) f += (int64_t)ld.N * (ld.K1 + ld.K2);
@@ -472,8 +508,11 @@ int train_squad_backward(osd_handle* h, hipStream_t s, const FwdWs& f, const Tra
   ta.spin_budget = std::min<unsigned long long>(h->chain_spin_budget, 20000000ull);
   ta.keep_scale = (float)(1.0 / (1.0 - (double)h->cfg.dropout_p)); ta.p_drop = h->cfg.dropout_p;
   ta.seed = B.seed; ta.row_offset = B.row_offset; ta.step = 0;
-  hipLaunchKernelGGL(k_pack_fragments_multi_t, dim3(64, (unsigned)npk), dim3(256), 0, s, pm, wpk);
-  OSD_HIP(hipGetLastError());
+  if (!h->sq_wpk_t_fresh) {      // else: packed by this step's forward launch (train_squad_forward), same list, same offsets
+    hipLaunchKernelGGL(k_pack_fragments_multi_t, dim3(64, (unsigned)npk), dim3(256), 0, s, pm, wpk);
+    OSD_HIP(hipGetLastError());
+  }
+  h->sq_wpk_t_fresh = false;
   hipLaunchKernelGGL(train_squad_bwd_kernel, dim3((unsigned)(panels * SQ_S)), dim3(SQ_THREADS), ts_lds_bytes(p.n_layers), s, ta);
   OSD_HIP(hipGetLastError());
   return OSD_OK;

@@ -71,7 +71,7 @@ int64_t train_squad_bwd_wpk_floats(const Arch& a);
 int train_squad_backward(osd_handle* h, hipStream_t s, const FwdWs& f, const TrainSquadBwdBufs& B, int64_t n, float* gact_units, float* wpk,
                          unsigned* bar_and_status, int64_t panels, float* loss_poison);
 int train_squad_forward(osd_handle* h, hipStream_t s, const FwdWs& ws, const TrunkIn& in, float* act_units, float* wpk, unsigned* bar_and_status,
-                        int64_t panels, float* loss_poison);
+                        int64_t panels, float* loss_poison, float* wpk_t = nullptr);
 // wgrad_group.hip
 struct WgPending;
 int wgrad_group_flush(osd_handle* h, hipStream_t s, int plan_index, const std::vector<WgPending>& pend, float* slabs, int64_t slab_floats,

@@ -101,6 +101,7 @@ struct osd_handle {
   int train_ksplit = 1;              // osd_set_option("train_ksplit", 0|1): two wave groups per workgroup in the training forward's GEMMs (gemm_glds.h)
   int dual_dgrad = 1;                // osd_set_option("dual_dgrad", 0|1): a decoder block's two input dgrads in one launch (k_gnbwd.hip)
   int cond_bwd_fused = 1;            // osd_set_option("cond_bwd_fused", 0|1): the conditioning branch's backward below h0 as one launch (k_cond_bwd, k_train.hip)
+  bool sq_wpk_t_fresh = false;       // the backward squads' transposed weight copies were packed by this step's forward launch (chain_squad.hip)
   int train_input_splitk = 0;        // osd_set_option("train_input_splitk"): K slices of input_proj in the training forward (0 / 1 = single pass)
   bool splitk_suspended = false;     // a chain-kernel fallback re-run in progress: no split-K (bit-identical to the chain kernel)
   int input_splitk = 0;              // osd_set_option("input_splitk"): 0 off (default: a row's result does not depend on how rows are chunked / sharded),

@@ -151,20 +151,24 @@ __global__ __launch_bounds__(256) void k_cond_bwd(const float* __restrict__ g_h0
     const float cv = (cond ? cond : u0)[(crow < rows ? crow : last_row) * (cond ? cd : 0) + (cj < cd ? cj : 0)];
     float4 v[4];
     for (int base = tid; base < R * q; base += 256 * 4) {      // 1 024 float4 at H0 = 256: one round of four loads
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = base + 256 * u, ic = i < R * q ? i : R * q - 1;
-        const int r = ic / q, c4 = ic - r * q;
-        const int64_t grow = row0 + r;
-        v[u] = *reinterpret_cast<const float4*>(g_h0 + (grow < rows ? grow : last_row) * H0 + 4 * c4);
-        if (grow >= rows) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      const float* src[4];
+      float* dst[4];
+      bool live[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {      // behind the end: the last element once more, to its own place
         const int i = base + 256 * u, ic = i < R * q ? i : R * q - 1;
         const int r = ic / q, c4 = ic - r * q;
-        *reinterpret_cast<float4*>(tile + r * ldt + 4 * c4) = v[u];
+        const int64_t grow = row0 + r;
+        live[u] = grow < rows;
+        src[u] = g_h0 + (live[u] ? grow : last_row) * H0 + 4 * c4;
+        dst[u] = tile + r * ldt + 4 * c4;
       }
+      __builtin_amdgcn_sched_barrier(0);      // addresses first, then the four loads back to back (hipcc had each load wait behind the previous one's use)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(src[u]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(dst[u]) = live[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     cb_t[tid & (R - 1)] = (g_temb && row < rows) ? tv : -1;
     cb_c[ci] = (cond && cj < cd && crow < rows) ? cv : 0.f;

@@ -574,7 +574,9 @@ int osd_train_loss_fwd_bwd(osd_handle* h, const float* x0, const float* cond, in
   if (W.sq_act && train_squad_ok(h, n)) {
     in.input_only = true;
     OSD_TRY(run_trunk(h, s, W.f, in));
-    OSD_TRY(train_squad_forward(h, s, W.f, in, W.sq_act, W.sq_wpk, W.sq_bar, W.sq_panels, loss_out));
+    // the step's backward as squads as well (backward_from's condition): both weight repacks in the forward's launch
+    const bool squad_bwd_next = grads && h->fused_gn_bwd && !events && !h->wgrad_mid_flush && W.sq_gact && h->train_squad >= 2;
+    OSD_TRY(train_squad_forward(h, s, W.f, in, W.sq_act, W.sq_wpk, W.sq_bar, W.sq_panels, loss_out, squad_bwd_next ? W.sq_wpk_t : nullptr));
   } else {
     OSD_TRY(run_trunk(h, s, W.f, in));
   }
